@@ -1,0 +1,145 @@
+/* C ABI of the MI355X path-tracing core (librt_amd.so).
+ *
+ * The reference (IcedLeon/Raytracing) has no plugin or FFI layer; its render loop is the nested
+ * loop of main.cpp:118-146, called by main() only.  This library replaces the BODY of that loop:
+ * the caller still builds the scene and the camera through the reference's class surface
+ * (main.cpp:109-116), flattens them into the plain arrays below, and makes one render call.
+ * Each entry point names the reference code it stands in for.
+ *
+ * Conventions: every function returns 0 on success or a negative rt_status; no exception or
+ * abort crosses the boundary; rt_last_error() gives the message of the last failure.  A context
+ * is bound to one GPU and is not re-entrant; distinct contexts are independent.
+ */
+#ifndef RT_AMD_H
+#define RT_AMD_H
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct rt_context rt_context;
+
+enum rt_status {
+    RT_OK = 0,
+    RT_ERR_INVALID = -1,      /* bad argument (null pointer, non-positive size, unknown material) */
+    RT_ERR_NO_DEVICE = -2,    /* no usable HIP device / ordinal out of range */
+    RT_ERR_HIP = -3,          /* a HIP runtime call failed; see rt_last_error */
+    RT_ERR_STATE = -4,        /* render requested before a scene and a camera were set */
+    RT_ERR_TOO_LARGE = -5     /* size beyond a documented limit */
+};
+
+/* Material::Scatter dispatch (material.h:55-59 has no type tag; the flatten pass assigns one). */
+enum rt_material { RT_LAMBERTIAN = 0, RT_METAL = 1, RT_DIELECTRIC = 2 };
+
+/* Kernel organisation for the bounce loop of Color() (main.cpp:13-39). */
+enum rt_mode {
+    RT_MODE_MEGAKERNEL = 0,   /* one lane per pixel, samples regenerated in-lane, scene in LDS */
+    RT_MODE_WAVEFRONT = 1     /* ray queues in HBM compacted with wave ballot/prefix counts */
+};
+
+/* The eight public fields of Camera (camera.h:13-21), copied one to one. */
+typedef struct rt_camera_pod {
+    float origin[3];
+    float lower_left_corner[3];
+    float horizontal[3];
+    float vertical[3];
+    float u[3], v[3], w[3];
+    float lens_radius;
+} rt_camera_pod;
+
+/* Parameters the reference hard-codes as locals: nx, ny, ns (main.cpp:87-89), the depth cap 50
+ * (main.cpp:22) and the hit interval lower bound 0.001 (main.cpp:17).
+ *
+ * Rows are image rows y counted from the TOP (PPM order, main.cpp:118 walks j = ny-1-y).  A call
+ * renders the bands b = band_first, band_first + band_step, ... where band b covers rows
+ * [b*band_rows, min((b+1)*band_rows, height)); its output holds exactly those rows, packed in
+ * increasing y.  band_first = 0, band_step = 1 renders the whole image.  Because every uniform is
+ * a pure function of (seed, pixel, sample, bounce), the assembled image does not depend on how
+ * the bands are split over GPUs. */
+typedef struct rt_params {
+    int32_t width, height;
+    int32_t spp;
+    int32_t max_depth;        /* 50 in the reference; at most RT_MAX_DEPTH */
+    float   tmin;             /* 0.001f in the reference */
+    uint64_t seed;            /* Philox key */
+    int32_t band_rows, band_first, band_step;
+    int32_t mode;             /* enum rt_mode */
+} rt_params;
+
+#define RT_MAX_DEPTH 64
+
+/* ---- lifetime ------------------------------------------------------------------------- */
+int rt_device_count(int *count);
+int rt_create(int device_ordinal, rt_context **out);
+void rt_destroy(rt_context *ctx);
+/* Message of the most recent failure on ctx (or of the most recent context-less failure when
+ * ctx is NULL).  The pointer stays valid until the next failing call. */
+const char *rt_last_error(const rt_context *ctx);
+
+/* ---- scene and camera ----------------------------------------------------------------- */
+/* Replaces walking HittableList::m_oList (hittablelist.h:10-15) of Sphere{m_oCenter, m_fRadius,
+ * m_oMaterial} (sphere.h:10-17) at render time: the caller hands over the flattened list once.
+ * Host pointers, n entries each; albedo_rgb holds 3*n floats (Lambertian::m_oAlbedo /
+ * Metal::m_oAlbedo; ignored for dielectrics); param is Metal::m_fFuzz (after the constructor's
+ * clamp, material.h:73-83) or Dielectric::m_fRefIdx.  The arrays are copied. */
+int rt_upload_scene(rt_context *ctx, int n, const float *cx, const float *cy, const float *cz,
+                    const float *radius, const int32_t *material, const float *albedo_rgb,
+                    const float *param);
+/* Replaces reading the Camera object inside GetRay (camera.cpp:46-53). */
+int rt_set_camera(rt_context *ctx, const rt_camera_pod *cam);
+
+/* ---- render: the loop body of main.cpp:118-141 ---------------------------------------- */
+/* Number of image rows / pixels the call described by p produces (0 on invalid p). */
+int64_t rt_owned_rows(const rt_params *p);
+int64_t rt_owned_pixels(const rt_params *p);
+
+/* Device-pointer form.  d_rgb_mean: 3 floats per owned pixel, the per-pixel mean `col / ns`
+ * before gamma (main.cpp:135); d_irgb: 3 int32 per owned pixel, int(255.99*sqrt(mean))
+ * (main.cpp:136-140).  Either may be NULL.  Work is enqueued on `stream` (a hipStream_t; NULL =
+ * the default stream) and the call returns without waiting. */
+int rt_render_device(rt_context *ctx, const rt_params *p, float *d_rgb_mean, int32_t *d_irgb,
+                     void *stream);
+/* Waits for the last rt_render_device on ctx and reports the closest-hit queries it traced (one
+ * per Color() invocation, the quantity RenderStats::rays_traced counts, main_modern.cpp:25-28)
+ * and the GPU time between the HIP events that bracket its kernels.  Either may be NULL. */
+int rt_render_stats(rt_context *ctx, uint64_t *rays, float *kernel_ms);
+/* Host-pointer convenience form: render, copy back, wait. */
+int rt_render(rt_context *ctx, const rt_params *p, float *h_rgb_mean, int32_t *h_irgb,
+              uint64_t *rays, float *kernel_ms);
+
+/* ---- output.ppm (main.cpp:91-97, 143-147) --------------------------------------------- */
+/* Formats "P3\n{w} {h}\n255\n" followed by one "r g b\n" line per pixel into buf.  Returns the
+ * number of bytes written, or the required capacity (negated) when cap is too small. */
+int64_t rt_format_ppm(const int32_t *irgb, int width, int height, char *buf, int64_t cap);
+/* Creates/truncates `path` and writes the P3 image. */
+int rt_write_ppm(const char *path, const int32_t *irgb, int width, int height);
+
+/* ---- unit-level entry points: the device functions on arrays -------------------------- */
+/* Each runs the same __device__ function the render kernels call, one element per lane, on host
+ * arrays of `n` elements.  They exist so that Sphere::Hit, the three Scatter functions and
+ * Camera::GetRay can be checked in isolation against vectors produced by the reference. */
+/* Sphere::Hit (sphere.cpp:15-52). in: ray_o[3n], ray_d[3n], center[3n], radius[n], tmin[n],
+ * tmax[n]; out: hit[n], t[n], p[3n], normal[3n] (front_face is dot(d, normal) <= 0, the test
+ * Dielectric::Scatter makes at material.h:148). */
+int rt_test_sphere_hit(rt_context *ctx, int n, const float *ray_o, const float *ray_d,
+                       const float *center, const float *radius, const float *tmin,
+                       const float *tmax, int32_t *hit, float *t, float *p, float *normal);
+/* Material::Scatter (material.h:85-91, 107-116, 132-186).  draws: draws_per_case rand() integers
+ * per case, consumed in call order as rand()/(RAND_MAX+1.0).  out: ret[n], attenuation[3n],
+ * out_o[3n], out_d[3n], used[n] (draws consumed). */
+int rt_test_scatter(rt_context *ctx, int n, const int32_t *material, const float *albedo_rgb,
+                    const float *param, const float *ray_o, const float *ray_d, const float *hit_p,
+                    const float *hit_n, const int32_t *draws, int draws_per_case, int32_t *ret,
+                    float *attenuation, float *out_o, float *out_d, int32_t *used);
+/* Camera::GetRay (camera.cpp:46-53) with an explicit unit-disk sample per case. */
+int rt_test_get_ray(rt_context *ctx, int n, const rt_camera_pod *cam, const float *s,
+                    const float *t, const float *disk_xy, float *ray_o, float *ray_d);
+/* Philox4x32-10 blocks: ctr[4n], key[2] -> out[4n]. */
+int rt_test_philox(rt_context *ctx, int n, const uint32_t *ctr, const uint32_t *key, uint32_t *out);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* RT_AMD_H */

@@ -1,0 +1,530 @@
+// HIP kernels (gfx950) and the extern "C" layer of librt_amd.so.  See include/rt_amd.h.
+#include <hip/hip_runtime.h>
+#include <cfloat>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <new>
+#include <string>
+#include <vector>
+#include "rt_amd.h"
+#include "rt_device.hpp"
+
+using namespace rt;
+
+// ============================================================================ device data layout
+// Scene records in HBM (built once per upload) and, for the megakernel, mirrored into LDS:
+//   geom[i] = (cx, cy, cz, r*r)       16 B  -- everything the sweep touches
+//   mat[i]  = (ar, ag, ab, param)     16 B  -- read once per hit
+//   aux[i]  = (radius, type)           8 B  -- read once per hit (normal = (p - c) / radius)
+struct Aux { float radius; int type; };
+
+struct RenderArgs {
+    const float4* geom; const float4* mat; const Aux* aux; int n;
+    CameraD cam;
+    int width, height, spp, max_depth; float tmin;
+    uint32_t k0, k1;
+    int band_rows, band_first, band_step, owned_rows;
+    float* rgb_mean; int32_t* irgb;
+    unsigned long long* ray_counter;
+};
+
+static constexpr int kBlock = 256;          // 4 waves; each wave owns an 8x8 pixel tile
+static constexpr int kLdsBytesPerSphere = 40;
+static constexpr int kMaxLdsSpheres = 1536; // 60 KB of LDS per block -> at least two blocks per CU
+
+// Compact owned row r -> image row y (from the top).
+__device__ __forceinline__ int owned_row_to_y(const RenderArgs& a, int r)
+{
+    const int k = r / a.band_rows;
+    return (a.band_first + k * a.band_step) * a.band_rows + (r - k * a.band_rows);
+}
+
+// ============================================================================ megakernel
+// One lane per pixel.  A lane walks its pixel's samples in order and, within a sample, the
+// bounces of Color() (main.cpp:13-39) iteratively; when a path ends the lane starts its next
+// sample at once, so every trip of the outer loop issues one closest-hit sweep for every lane
+// that still has work.  The attenuation product of the recursion, a0*(a1*(...*sky)), is formed
+// innermost-first from a per-lane stack of hit indices so that it rounds exactly as the
+// reference's recursion does.
+template <bool kLds>
+__global__ void __launch_bounds__(kBlock) k_render_mega(const RenderArgs a)
+{
+    extern __shared__ float4 smem[];
+    float4* s_geom = smem;
+    float4* s_mat = smem + a.n;
+    Aux* s_aux = reinterpret_cast<Aux*>(smem + 2 * a.n);
+    __shared__ unsigned long long s_rays;
+    if (threadIdx.x == 0) s_rays = 0;
+    if (kLds) {
+        for (int i = threadIdx.x; i < a.n; i += kBlock) { s_geom[i] = a.geom[i]; s_mat[i] = a.mat[i]; s_aux[i] = a.aux[i]; }
+    }
+    __syncthreads();
+
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int i = blockIdx.x * 16 + (wave & 1) * 8 + (lane & 7);
+    const int r = blockIdx.y * 16 + (wave >> 1) * 8 + (lane >> 3);
+    const int y = owned_row_to_y(a, r < a.owned_rows ? r : 0);
+    const bool valid = (i < a.width) && (r < a.owned_rows) && (y < a.height);
+
+    uint32_t rays = 0;
+    if (valid) {
+        const int j = a.height - 1 - y;
+        const uint32_t pix = (uint32_t)j * (uint32_t)a.width + (uint32_t)i;
+        KeyedUniforms U; U.k0 = a.k0; U.k1 = a.k1; U.slot(pix, 0, 0);
+        uint16_t stack[RT_MAX_DEPTH];
+        V3 col = mk(0.0f, 0.0f, 0.0f);
+        RayD ray; int depth = 0; int smp = 0;
+        const float fnx = (float)a.width, fny = (float)a.height;
+
+        auto camera_ray = [&](int s) {
+            U.slot(pix, (uint32_t)s, 0);
+            const float ju = U.f(), jv = U.f();
+            const float fu = (float)((double)i + (double)ju) / fnx;
+            const float fv = (float)((double)j + (double)jv) / fny;
+            float dx = 0.0f, dy = 0.0f;
+            if (a.cam.lens_radius > 0.0f) {
+                uint32_t grp = 1;
+                do {
+                    const U4 w = philox4x32_10(pix, (uint32_t)s, 0, grp, a.k0, a.k1);
+                    dx = 2.0f * u01(w.x) - 1.0f; dy = 2.0f * u01(w.y) - 1.0f; ++grp;
+                } while ((dx * dx) + (dy * dy) + 0.0f >= 1.0f);
+            }
+            ray = get_ray(a.cam, fu, fv, dx, dy);
+            depth = 0;
+        };
+        camera_ray(0);
+
+        while (smp < a.spp) {
+            // ---- HittableList::Hit (hittablelist.cpp:13-31) over Sphere::Hit (sphere.cpp:15-52)
+            float closest = FLT_MAX; int hit = -1;
+            const float qa = dot(ray.d, ray.d);
+            for (int k = 0; k < a.n; ++k) {
+                const float4 g = kLds ? s_geom[k] : a.geom[k];
+                const V3 oc = ray.o - mk(g.x, g.y, g.z);
+                const float b = dot(oc, ray.d);
+                const float cc = dot(oc, oc) - g.w;
+                const float desc = b * b - qa * cc;
+                if (desc > 0.0f) {
+                    const float sq = sqrtf(desc);
+                    float temp = (-b - sq) / qa;
+                    if (!(temp < closest && temp > a.tmin)) temp = (-b + sq) / qa;
+                    if (temp < closest && temp > a.tmin) { closest = temp; hit = k; }
+                }
+            }
+            ++rays;
+            V3 sample; bool done;
+            if (hit >= 0) {
+                const float4 g = kLds ? s_geom[hit] : a.geom[hit];
+                const float4 m = kLds ? s_mat[hit] : a.mat[hit];
+                const Aux x = kLds ? s_aux[hit] : a.aux[hit];
+                const V3 p = ray.o + closest * ray.d;
+                const V3 nrm = (p - mk(g.x, g.y, g.z)) / x.radius;
+                V3 att; RayD out; bool cont = false;
+                if (depth < a.max_depth) {
+                    U.slot(pix, (uint32_t)smp, (uint32_t)depth + 1u);
+                    cont = scatter(x.type, mk(m.x, m.y, m.z), m.w, ray, p, nrm, U, att, out);
+                }
+                if (cont) { stack[depth] = (uint16_t)hit; ++depth; ray = out; done = false; }
+                else { sample = mk(0.0f, 0.0f, 0.0f); done = true; }
+            } else {
+                sample = sky(ray.d);
+                for (int k = depth - 1; k >= 0; --k) {
+                    const float4 m = kLds ? s_mat[stack[k]] : a.mat[stack[k]];
+                    sample = mk(m.x, m.y, m.z) * sample;
+                }
+                done = true;
+            }
+            if (done) {
+                col = col + sample;
+                ++smp;
+                if (smp < a.spp) camera_ray(smp);
+            }
+        }
+        const float inv = 1.0f / (float)a.spp;          // Vec3::operator/=(float), vec3.cpp:109-118
+        const float mr = col.x * inv, mg = col.y * inv, mb = col.z * inv;
+        const size_t o = ((size_t)r * a.width + i) * 3;
+        if (a.rgb_mean) { a.rgb_mean[o] = mr; a.rgb_mean[o + 1] = mg; a.rgb_mean[o + 2] = mb; }
+        if (a.irgb) { a.irgb[o] = quantise(mr); a.irgb[o + 1] = quantise(mg); a.irgb[o + 2] = quantise(mb); }
+    }
+    if (rays) atomicAdd(&s_rays, (unsigned long long)rays);
+    __syncthreads();
+    if (threadIdx.x == 0 && s_rays) atomicAdd(a.ray_counter, s_rays);
+}
+
+// ============================================================================ unit-level kernels
+__global__ void k_test_sphere_hit(int n, const float* ro, const float* rd, const float* c, const float* radius,
+                                  const float* tmin, const float* tmax, int32_t* hit, float* t, float* p, float* nrm)
+{
+    const int e = blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= n) return;
+    RayD r; r.o = mk(ro[3 * e], ro[3 * e + 1], ro[3 * e + 2]); r.d = mk(rd[3 * e], rd[3 * e + 1], rd[3 * e + 2]);
+    HitD rec; rec.t = 0; rec.p = mk(0, 0, 0); rec.n = mk(0, 0, 0);
+    const bool h = sphere_hit(r, mk(c[3 * e], c[3 * e + 1], c[3 * e + 2]), radius[e], tmin[e], tmax[e], rec);
+    hit[e] = h ? 1 : 0; t[e] = h ? rec.t : 0.0f;
+    p[3 * e] = h ? rec.p.x : 0; p[3 * e + 1] = h ? rec.p.y : 0; p[3 * e + 2] = h ? rec.p.z : 0;
+    nrm[3 * e] = h ? rec.n.x : 0; nrm[3 * e + 1] = h ? rec.n.y : 0; nrm[3 * e + 2] = h ? rec.n.z : 0;
+}
+
+__global__ void k_test_scatter(int n, const int32_t* type, const float* albedo, const float* param, const float* ro,
+                               const float* rd, const float* hp, const float* hn, const int32_t* draws, int per,
+                               int32_t* ret, float* att, float* oo, float* od, int32_t* used)
+{
+    const int e = blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= n) return;
+    RayD in; in.o = mk(ro[3 * e], ro[3 * e + 1], ro[3 * e + 2]); in.d = mk(rd[3 * e], rd[3 * e + 1], rd[3 * e + 2]);
+    ReplayUniforms U; U.draws = draws + (size_t)e * per; U.pos = 0;
+    V3 a = mk(0, 0, 0); RayD out; out.o = mk(0, 0, 0); out.d = mk(0, 0, 0);
+    const bool rv = scatter(type[e], mk(albedo[3 * e], albedo[3 * e + 1], albedo[3 * e + 2]), param[e], in,
+                            mk(hp[3 * e], hp[3 * e + 1], hp[3 * e + 2]), mk(hn[3 * e], hn[3 * e + 1], hn[3 * e + 2]), U, a, out);
+    ret[e] = rv ? 1 : 0; used[e] = U.pos;
+    att[3 * e] = a.x; att[3 * e + 1] = a.y; att[3 * e + 2] = a.z;
+    oo[3 * e] = out.o.x; oo[3 * e + 1] = out.o.y; oo[3 * e + 2] = out.o.z;
+    od[3 * e] = out.d.x; od[3 * e + 1] = out.d.y; od[3 * e + 2] = out.d.z;
+}
+
+__global__ void k_test_get_ray(int n, const CameraD cam, const float* s, const float* t, const float* disk, float* ro, float* rd)
+{
+    const int e = blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= n) return;
+    const RayD r = get_ray(cam, s[e], t[e], disk[2 * e], disk[2 * e + 1]);
+    ro[3 * e] = r.o.x; ro[3 * e + 1] = r.o.y; ro[3 * e + 2] = r.o.z;
+    rd[3 * e] = r.d.x; rd[3 * e + 1] = r.d.y; rd[3 * e + 2] = r.d.z;
+}
+
+__global__ void k_test_philox(int n, const uint32_t* ctr, uint32_t k0, uint32_t k1, uint32_t* out)
+{
+    const int e = blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= n) return;
+    const U4 w = philox4x32_10(ctr[4 * e], ctr[4 * e + 1], ctr[4 * e + 2], ctr[4 * e + 3], k0, k1);
+    out[4 * e] = w.x; out[4 * e + 1] = w.y; out[4 * e + 2] = w.z; out[4 * e + 3] = w.w;
+}
+
+// ============================================================================ host side
+struct rt_context {
+    int device = -1;
+    std::string error;
+    float4* d_geom = nullptr; float4* d_mat = nullptr; Aux* d_aux = nullptr; int n = 0;
+    bool have_camera = false; CameraD cam{};
+    unsigned long long* d_rays = nullptr;
+    hipEvent_t ev0 = nullptr, ev1 = nullptr; hipStream_t last_stream = nullptr; bool pending = false;
+};
+
+static thread_local std::string g_error;
+
+static int fail(rt_context* ctx, int code, const char* fmt, ...)
+{
+    char buf[512];
+    va_list ap; va_start(ap, fmt); vsnprintf(buf, sizeof buf, fmt, ap); va_end(ap);
+    if (ctx) ctx->error = buf; else g_error = buf;
+    return code;
+}
+#define HIP_TRY(ctx, call) do { hipError_t e_ = (call); if (e_ != hipSuccess) return fail(ctx, RT_ERR_HIP, "%s failed: %s", #call, hipGetErrorString(e_)); } while (0)
+
+static CameraD to_device(const rt_camera_pod& c)
+{
+    CameraD d;
+    d.origin = { c.origin[0], c.origin[1], c.origin[2] };
+    d.llc = { c.lower_left_corner[0], c.lower_left_corner[1], c.lower_left_corner[2] };
+    d.horiz = { c.horizontal[0], c.horizontal[1], c.horizontal[2] };
+    d.vert = { c.vertical[0], c.vertical[1], c.vertical[2] };
+    d.u = { c.u[0], c.u[1], c.u[2] };
+    d.v = { c.v[0], c.v[1], c.v[2] };
+    d.lens_radius = c.lens_radius;
+    return d;
+}
+
+static bool params_ok(const rt_params* p)
+{
+    return p && p->width > 0 && p->height > 0 && p->spp > 0 && p->max_depth >= 0 && p->max_depth <= RT_MAX_DEPTH &&
+           p->band_rows > 0 && p->band_first >= 0 && p->band_step > 0 &&
+           (p->mode == RT_MODE_MEGAKERNEL || p->mode == RT_MODE_WAVEFRONT);
+}
+
+namespace {
+struct DevBuf {
+    void* p = nullptr;
+    ~DevBuf() { if (p) (void)hipFree(p); }
+    hipError_t up(const void* h, size_t bytes) { hipError_t e = hipMalloc(&p, bytes ? bytes : 4); if (e == hipSuccess && h && bytes) e = hipMemcpy(p, h, bytes, hipMemcpyHostToDevice); return e; }
+    hipError_t down(void* h, size_t bytes) { return hipMemcpy(h, p, bytes, hipMemcpyDeviceToHost); }
+    template <class T> T* as() { return static_cast<T*>(p); }
+};
+}
+
+extern "C" {
+
+int rt_device_count(int* count)
+{
+    if (!count) return fail(nullptr, RT_ERR_INVALID, "rt_device_count: null output");
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess) { *count = 0; return fail(nullptr, RT_ERR_NO_DEVICE, "hipGetDeviceCount: %s", hipGetErrorString(e)); }
+    *count = n;
+    return RT_OK;
+}
+
+int rt_create(int device_ordinal, rt_context** out)
+{
+    if (!out) return fail(nullptr, RT_ERR_INVALID, "rt_create: null output");
+    *out = nullptr;
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess || n <= 0) return fail(nullptr, RT_ERR_NO_DEVICE, "rt_create: no HIP device visible");
+    if (device_ordinal < 0 || device_ordinal >= n) return fail(nullptr, RT_ERR_NO_DEVICE, "rt_create: device %d out of range [0,%d)", device_ordinal, n);
+    rt_context* ctx = new (std::nothrow) rt_context;
+    if (!ctx) return fail(nullptr, RT_ERR_HIP, "rt_create: out of host memory");
+    ctx->device = device_ordinal;
+    hipError_t e = hipSetDevice(device_ordinal);
+    if (e == hipSuccess) e = hipMalloc(&ctx->d_rays, sizeof(unsigned long long));
+    if (e == hipSuccess) e = hipEventCreate(&ctx->ev0);
+    if (e == hipSuccess) e = hipEventCreate(&ctx->ev1);
+    if (e != hipSuccess) { fail(nullptr, RT_ERR_HIP, "rt_create: %s", hipGetErrorString(e)); rt_destroy(ctx); return RT_ERR_HIP; }
+    *out = ctx;
+    return RT_OK;
+}
+
+void rt_destroy(rt_context* ctx)
+{
+    if (!ctx) return;
+    (void)hipSetDevice(ctx->device);
+    if (ctx->pending) (void)hipStreamSynchronize(ctx->last_stream);
+    (void)hipFree(ctx->d_geom); (void)hipFree(ctx->d_mat); (void)hipFree(ctx->d_aux); (void)hipFree(ctx->d_rays);
+    if (ctx->ev0) (void)hipEventDestroy(ctx->ev0);
+    if (ctx->ev1) (void)hipEventDestroy(ctx->ev1);
+    delete ctx;
+}
+
+const char* rt_last_error(const rt_context* ctx) { return ctx ? ctx->error.c_str() : g_error.c_str(); }
+
+int rt_upload_scene(rt_context* ctx, int n, const float* cx, const float* cy, const float* cz, const float* radius,
+                    const int32_t* material, const float* albedo_rgb, const float* param)
+{
+    if (!ctx) return fail(nullptr, RT_ERR_INVALID, "rt_upload_scene: null context");
+    if (n <= 0 || !cx || !cy || !cz || !radius || !material || !albedo_rgb || !param) return fail(ctx, RT_ERR_INVALID, "rt_upload_scene: null array or n <= 0");
+    if (n > 65535) return fail(ctx, RT_ERR_TOO_LARGE, "rt_upload_scene: %d spheres exceeds the 65535 limit of the 16-bit hit stack", n);
+    std::vector<float4> geom(n), mat(n); std::vector<Aux> aux(n);
+    for (int i = 0; i < n; ++i) {
+        if (material[i] < RT_LAMBERTIAN || material[i] > RT_DIELECTRIC) return fail(ctx, RT_ERR_INVALID, "rt_upload_scene: sphere %d has unknown material %d", i, material[i]);
+        geom[i] = make_float4(cx[i], cy[i], cz[i], radius[i] * radius[i]);
+        const bool glass = material[i] == RT_DIELECTRIC;   // Dielectric::Scatter sets attenuation (1,1,1)
+        mat[i] = make_float4(glass ? 1.0f : albedo_rgb[3 * i], glass ? 1.0f : albedo_rgb[3 * i + 1], glass ? 1.0f : albedo_rgb[3 * i + 2], param[i]);
+        aux[i].radius = radius[i]; aux[i].type = material[i];
+    }
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    if (ctx->pending) { HIP_TRY(ctx, hipStreamSynchronize(ctx->last_stream)); ctx->pending = false; }
+    (void)hipFree(ctx->d_geom); (void)hipFree(ctx->d_mat); (void)hipFree(ctx->d_aux);
+    ctx->d_geom = nullptr; ctx->d_mat = nullptr; ctx->d_aux = nullptr; ctx->n = 0;
+    HIP_TRY(ctx, hipMalloc(&ctx->d_geom, sizeof(float4) * n));
+    HIP_TRY(ctx, hipMalloc(&ctx->d_mat, sizeof(float4) * n));
+    HIP_TRY(ctx, hipMalloc(&ctx->d_aux, sizeof(Aux) * n));
+    HIP_TRY(ctx, hipMemcpy(ctx->d_geom, geom.data(), sizeof(float4) * n, hipMemcpyHostToDevice));
+    HIP_TRY(ctx, hipMemcpy(ctx->d_mat, mat.data(), sizeof(float4) * n, hipMemcpyHostToDevice));
+    HIP_TRY(ctx, hipMemcpy(ctx->d_aux, aux.data(), sizeof(Aux) * n, hipMemcpyHostToDevice));
+    ctx->n = n;
+    return RT_OK;
+}
+
+int rt_set_camera(rt_context* ctx, const rt_camera_pod* cam)
+{
+    if (!ctx) return fail(nullptr, RT_ERR_INVALID, "rt_set_camera: null context");
+    if (!cam) return fail(ctx, RT_ERR_INVALID, "rt_set_camera: null camera");
+    ctx->cam = to_device(*cam);
+    ctx->have_camera = true;
+    return RT_OK;
+}
+
+int64_t rt_owned_rows(const rt_params* p)
+{
+    if (!params_ok(p)) return 0;
+    const int64_t nbands = ((int64_t)p->height + p->band_rows - 1) / p->band_rows;
+    int64_t rows = 0;
+    for (int64_t b = p->band_first; b < nbands; b += p->band_step) {
+        const int64_t y0 = b * p->band_rows, y1 = y0 + p->band_rows;
+        rows += (y1 < p->height ? y1 : p->height) - y0;
+    }
+    return rows;
+}
+
+int64_t rt_owned_pixels(const rt_params* p) { return rt_owned_rows(p) * (p ? p->width : 0); }
+
+int rt_render_device(rt_context* ctx, const rt_params* p, float* d_rgb_mean, int32_t* d_irgb, void* stream)
+{
+    if (!ctx) return fail(nullptr, RT_ERR_INVALID, "rt_render_device: null context");
+    if (!params_ok(p)) return fail(ctx, RT_ERR_INVALID, "rt_render_device: invalid parameters");
+    if (!ctx->n || !ctx->have_camera) return fail(ctx, RT_ERR_STATE, "rt_render_device: scene and camera must be set first");
+    if (p->mode == RT_MODE_WAVEFRONT) return fail(ctx, RT_ERR_INVALID, "rt_render_device: wavefront mode is not built into this library");
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    const int owned = (int)rt_owned_rows(p);
+    HIP_TRY(ctx, hipMemsetAsync(ctx->d_rays, 0, sizeof(unsigned long long), st));
+    if (owned > 0) {
+        RenderArgs a;
+        a.geom = ctx->d_geom; a.mat = ctx->d_mat; a.aux = ctx->d_aux; a.n = ctx->n; a.cam = ctx->cam;
+        a.width = p->width; a.height = p->height; a.spp = p->spp; a.max_depth = p->max_depth; a.tmin = p->tmin;
+        a.k0 = (uint32_t)p->seed; a.k1 = (uint32_t)(p->seed >> 32);
+        a.band_rows = p->band_rows; a.band_first = p->band_first; a.band_step = p->band_step; a.owned_rows = owned;
+        a.rgb_mean = d_rgb_mean; a.irgb = d_irgb; a.ray_counter = ctx->d_rays;
+        const dim3 grid((p->width + 15) / 16, (owned + 15) / 16), block(kBlock);
+        HIP_TRY(ctx, hipEventRecord(ctx->ev0, st));
+        if (ctx->n <= kMaxLdsSpheres) {
+            hipLaunchKernelGGL(k_render_mega<true>, grid, block, (size_t)ctx->n * kLdsBytesPerSphere, st, a);
+        } else {
+            hipLaunchKernelGGL(k_render_mega<false>, grid, block, 0, st, a);
+        }
+        HIP_TRY(ctx, hipGetLastError());
+        HIP_TRY(ctx, hipEventRecord(ctx->ev1, st));
+    } else {
+        HIP_TRY(ctx, hipEventRecord(ctx->ev0, st));
+        HIP_TRY(ctx, hipEventRecord(ctx->ev1, st));
+    }
+    ctx->last_stream = st; ctx->pending = true;
+    return RT_OK;
+}
+
+int rt_render_stats(rt_context* ctx, uint64_t* rays, float* kernel_ms)
+{
+    if (!ctx) return fail(nullptr, RT_ERR_INVALID, "rt_render_stats: null context");
+    if (!ctx->pending) return fail(ctx, RT_ERR_STATE, "rt_render_stats: no render has been enqueued");
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    HIP_TRY(ctx, hipEventSynchronize(ctx->ev1));
+    if (kernel_ms) HIP_TRY(ctx, hipEventElapsedTime(kernel_ms, ctx->ev0, ctx->ev1));
+    if (rays) {
+        unsigned long long r = 0;
+        HIP_TRY(ctx, hipMemcpyAsync(&r, ctx->d_rays, sizeof r, hipMemcpyDeviceToHost, ctx->last_stream));
+        HIP_TRY(ctx, hipStreamSynchronize(ctx->last_stream));
+        *rays = r;
+    }
+    return RT_OK;
+}
+
+int rt_render(rt_context* ctx, const rt_params* p, float* h_rgb_mean, int32_t* h_irgb, uint64_t* rays, float* kernel_ms)
+{
+    if (!ctx) return fail(nullptr, RT_ERR_INVALID, "rt_render: null context");
+    if (!params_ok(p)) return fail(ctx, RT_ERR_INVALID, "rt_render: invalid parameters");
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    const size_t npx = (size_t)rt_owned_pixels(p);
+    float* d_rgb = nullptr; int32_t* d_i = nullptr;
+    int rc = RT_OK;
+    if (h_rgb_mean && npx) { hipError_t e = hipMalloc(&d_rgb, npx * 3 * sizeof(float)); if (e != hipSuccess) return fail(ctx, RT_ERR_HIP, "rt_render: hipMalloc: %s", hipGetErrorString(e)); }
+    if (h_irgb && npx) { hipError_t e = hipMalloc(&d_i, npx * 3 * sizeof(int32_t)); if (e != hipSuccess) { (void)hipFree(d_rgb); return fail(ctx, RT_ERR_HIP, "rt_render: hipMalloc: %s", hipGetErrorString(e)); } }
+    rc = rt_render_device(ctx, p, d_rgb, d_i, nullptr);
+    if (rc == RT_OK) rc = rt_render_stats(ctx, rays, kernel_ms);
+    if (rc == RT_OK && d_rgb) { hipError_t e = hipMemcpy(h_rgb_mean, d_rgb, npx * 3 * sizeof(float), hipMemcpyDeviceToHost); if (e != hipSuccess) rc = fail(ctx, RT_ERR_HIP, "rt_render: copy back: %s", hipGetErrorString(e)); }
+    if (rc == RT_OK && d_i) { hipError_t e = hipMemcpy(h_irgb, d_i, npx * 3 * sizeof(int32_t), hipMemcpyDeviceToHost); if (e != hipSuccess) rc = fail(ctx, RT_ERR_HIP, "rt_render: copy back: %s", hipGetErrorString(e)); }
+    (void)hipFree(d_rgb); (void)hipFree(d_i);
+    return rc;
+}
+
+// ---------------------------------------------------------------------------- output.ppm
+static inline char* put_int(char* q, int32_t v)
+{
+    char tmp[12]; int n = 0;
+    uint32_t u = v < 0 ? 0u - (uint32_t)v : (uint32_t)v;
+    do { tmp[n++] = (char)('0' + u % 10); u /= 10; } while (u);
+    if (v < 0) *q++ = '-';
+    while (n) *q++ = tmp[--n];
+    return q;
+}
+
+int64_t rt_format_ppm(const int32_t* irgb, int width, int height, char* buf, int64_t cap)
+{
+    if (!irgb || width <= 0 || height <= 0) return 0;
+    const int64_t worst = 32 + (int64_t)width * height * 36;   // three ints of up to 11 chars + separators
+    char head[48];
+    const int hn = snprintf(head, sizeof head, "P3\n%d %d\n255\n", width, height);
+    if (!buf || cap < worst) {
+        // exact size pass
+        int64_t need = hn; char t[16];
+        for (int64_t k = 0; k < (int64_t)width * height * 3; ++k) need += (put_int(t, irgb[k]) - t) + 1;
+        if (!buf || cap < need) return -need;
+    }
+    char* q = buf; memcpy(q, head, hn); q += hn;
+    for (int64_t px = 0; px < (int64_t)width * height; ++px) {
+        q = put_int(q, irgb[3 * px]); *q++ = ' ';
+        q = put_int(q, irgb[3 * px + 1]); *q++ = ' ';
+        q = put_int(q, irgb[3 * px + 2]); *q++ = '\n';
+    }
+    return q - buf;
+}
+
+int rt_write_ppm(const char* path, const int32_t* irgb, int width, int height)
+{
+    if (!path || !irgb || width <= 0 || height <= 0) return fail(nullptr, RT_ERR_INVALID, "rt_write_ppm: bad argument");
+    const int64_t need = -rt_format_ppm(irgb, width, height, nullptr, 0);
+    std::vector<char> buf((size_t)need);
+    const int64_t n = rt_format_ppm(irgb, width, height, buf.data(), need);
+    FILE* f = fopen(path, "wb");
+    if (!f) return fail(nullptr, RT_ERR_INVALID, "rt_write_ppm: cannot open %s", path);
+    const size_t w = fwrite(buf.data(), 1, (size_t)n, f);
+    fclose(f);
+    return w == (size_t)n ? RT_OK : fail(nullptr, RT_ERR_INVALID, "rt_write_ppm: short write to %s", path);
+}
+
+// ---------------------------------------------------------------------------- unit-level entry points
+
+int rt_test_sphere_hit(rt_context* ctx, int n, const float* ray_o, const float* ray_d, const float* center, const float* radius,
+                       const float* tmin, const float* tmax, int32_t* hit, float* t, float* p, float* normal)
+{
+    if (!ctx) return fail(nullptr, RT_ERR_INVALID, "rt_test_sphere_hit: null context");
+    if (n <= 0 || !ray_o || !ray_d || !center || !radius || !tmin || !tmax || !hit || !t || !p || !normal) return fail(ctx, RT_ERR_INVALID, "rt_test_sphere_hit: bad argument");
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    DevBuf o, d, c, r, a, b, oh, ot, op, on;
+    const size_t f3 = sizeof(float) * 3 * n, f1 = sizeof(float) * n;
+    HIP_TRY(ctx, o.up(ray_o, f3)); HIP_TRY(ctx, d.up(ray_d, f3)); HIP_TRY(ctx, c.up(center, f3)); HIP_TRY(ctx, r.up(radius, f1));
+    HIP_TRY(ctx, a.up(tmin, f1)); HIP_TRY(ctx, b.up(tmax, f1));
+    HIP_TRY(ctx, oh.up(nullptr, sizeof(int32_t) * n)); HIP_TRY(ctx, ot.up(nullptr, f1)); HIP_TRY(ctx, op.up(nullptr, f3)); HIP_TRY(ctx, on.up(nullptr, f3));
+    hipLaunchKernelGGL(k_test_sphere_hit, dim3((n + 63) / 64), dim3(64), 0, 0, n, o.as<float>(), d.as<float>(), c.as<float>(), r.as<float>(),
+                       a.as<float>(), b.as<float>(), oh.as<int32_t>(), ot.as<float>(), op.as<float>(), on.as<float>());
+    HIP_TRY(ctx, hipGetLastError()); HIP_TRY(ctx, hipDeviceSynchronize());
+    HIP_TRY(ctx, oh.down(hit, sizeof(int32_t) * n)); HIP_TRY(ctx, ot.down(t, f1)); HIP_TRY(ctx, op.down(p, f3)); HIP_TRY(ctx, on.down(normal, f3));
+    return RT_OK;
+}
+
+int rt_test_scatter(rt_context* ctx, int n, const int32_t* material, const float* albedo_rgb, const float* param, const float* ray_o,
+                    const float* ray_d, const float* hit_p, const float* hit_n, const int32_t* draws, int draws_per_case,
+                    int32_t* ret, float* attenuation, float* out_o, float* out_d, int32_t* used)
+{
+    if (!ctx) return fail(nullptr, RT_ERR_INVALID, "rt_test_scatter: null context");
+    if (n <= 0 || draws_per_case <= 0 || !material || !albedo_rgb || !param || !ray_o || !ray_d || !hit_p || !hit_n || !draws || !ret || !attenuation || !out_o || !out_d || !used)
+        return fail(ctx, RT_ERR_INVALID, "rt_test_scatter: bad argument");
+    for (int i = 0; i < n; ++i) if (material[i] < 0 || material[i] > 2) return fail(ctx, RT_ERR_INVALID, "rt_test_scatter: unknown material %d", material[i]);
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    DevBuf m, al, pa, o, d, hp, hn, dr, r, at, oo, od, us;
+    const size_t f3 = sizeof(float) * 3 * n, f1 = sizeof(float) * n, i1 = sizeof(int32_t) * n;
+    HIP_TRY(ctx, m.up(material, i1)); HIP_TRY(ctx, al.up(albedo_rgb, f3)); HIP_TRY(ctx, pa.up(param, f1)); HIP_TRY(ctx, o.up(ray_o, f3));
+    HIP_TRY(ctx, d.up(ray_d, f3)); HIP_TRY(ctx, hp.up(hit_p, f3)); HIP_TRY(ctx, hn.up(hit_n, f3)); HIP_TRY(ctx, dr.up(draws, sizeof(int32_t) * (size_t)n * draws_per_case));
+    HIP_TRY(ctx, r.up(nullptr, i1)); HIP_TRY(ctx, at.up(nullptr, f3)); HIP_TRY(ctx, oo.up(nullptr, f3)); HIP_TRY(ctx, od.up(nullptr, f3)); HIP_TRY(ctx, us.up(nullptr, i1));
+    hipLaunchKernelGGL(k_test_scatter, dim3((n + 63) / 64), dim3(64), 0, 0, n, m.as<int32_t>(), al.as<float>(), pa.as<float>(), o.as<float>(), d.as<float>(),
+                       hp.as<float>(), hn.as<float>(), dr.as<int32_t>(), draws_per_case, r.as<int32_t>(), at.as<float>(), oo.as<float>(), od.as<float>(), us.as<int32_t>());
+    HIP_TRY(ctx, hipGetLastError()); HIP_TRY(ctx, hipDeviceSynchronize());
+    HIP_TRY(ctx, r.down(ret, i1)); HIP_TRY(ctx, at.down(attenuation, f3)); HIP_TRY(ctx, oo.down(out_o, f3)); HIP_TRY(ctx, od.down(out_d, f3)); HIP_TRY(ctx, us.down(used, i1));
+    return RT_OK;
+}
+
+int rt_test_get_ray(rt_context* ctx, int n, const rt_camera_pod* cam, const float* s, const float* t, const float* disk_xy, float* ray_o, float* ray_d)
+{
+    if (!ctx) return fail(nullptr, RT_ERR_INVALID, "rt_test_get_ray: null context");
+    if (n <= 0 || !cam || !s || !t || !disk_xy || !ray_o || !ray_d) return fail(ctx, RT_ERR_INVALID, "rt_test_get_ray: bad argument");
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    DevBuf ds, dt, dd, o, d;
+    const size_t f3 = sizeof(float) * 3 * n, f1 = sizeof(float) * n;
+    HIP_TRY(ctx, ds.up(s, f1)); HIP_TRY(ctx, dt.up(t, f1)); HIP_TRY(ctx, dd.up(disk_xy, 2 * f1)); HIP_TRY(ctx, o.up(nullptr, f3)); HIP_TRY(ctx, d.up(nullptr, f3));
+    hipLaunchKernelGGL(k_test_get_ray, dim3((n + 63) / 64), dim3(64), 0, 0, n, to_device(*cam), ds.as<float>(), dt.as<float>(), dd.as<float>(), o.as<float>(), d.as<float>());
+    HIP_TRY(ctx, hipGetLastError()); HIP_TRY(ctx, hipDeviceSynchronize());
+    HIP_TRY(ctx, o.down(ray_o, f3)); HIP_TRY(ctx, d.down(ray_d, f3));
+    return RT_OK;
+}
+
+int rt_test_philox(rt_context* ctx, int n, const uint32_t* ctr, const uint32_t* key, uint32_t* out)
+{
+    if (!ctx) return fail(nullptr, RT_ERR_INVALID, "rt_test_philox: null context");
+    if (n <= 0 || !ctr || !key || !out) return fail(ctx, RT_ERR_INVALID, "rt_test_philox: bad argument");
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    DevBuf c, o;
+    HIP_TRY(ctx, c.up(ctr, sizeof(uint32_t) * 4 * n)); HIP_TRY(ctx, o.up(nullptr, sizeof(uint32_t) * 4 * n));
+    hipLaunchKernelGGL(k_test_philox, dim3((n + 63) / 64), dim3(64), 0, 0, n, c.as<uint32_t>(), key[0], key[1], o.as<uint32_t>());
+    HIP_TRY(ctx, hipGetLastError()); HIP_TRY(ctx, hipDeviceSynchronize());
+    HIP_TRY(ctx, o.down(out, sizeof(uint32_t) * 4 * n));
+    return RT_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,64 @@
+"""The C-ABI library loads without a GPU and exports every symbol include/rt_amd.h declares."""
+import ctypes as C
+import os
+import re
+
+import numpy as np
+
+import raytracing_amd as R
+from raytracing_amd import _lib
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _declared():
+    text = open(os.path.join(ROOT, "include", "rt_amd.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(rt_[a-z_0-9]+)\s*\(", text)))
+
+
+def test_every_declared_symbol_is_exported():
+    L = R.load_library()
+    names = _declared()
+    assert len(names) >= 15
+    for n in names:
+        assert hasattr(L, n), n
+    assert sorted(_lib.EXPORTS) == names
+
+
+def test_struct_layouts_match_header():
+    assert C.sizeof(R.CameraPod) == 22 * 4
+    assert C.sizeof(R.Params) == 48 and R.Params.seed.offset == 24 and R.Params.mode.offset == 44
+
+
+def test_owned_rows_banding():
+    L = R.load_library()
+    P = R.Renderer.params
+    assert L.rt_owned_rows(C.byref(P(10, 800, 1))) == 800
+    # interleaved 8-row bands over 8 ranks cover every row exactly once
+    assert sum(L.rt_owned_rows(C.byref(P(10, 2160, 1, band_rows=8, band_first=r, band_step=8))) for r in range(8)) == 2160
+    # ragged last band
+    assert [L.rt_owned_rows(C.byref(P(10, 50, 1, band_rows=16, band_first=r, band_step=2))) for r in range(2)] == [32, 18]
+    assert L.rt_owned_rows(C.byref(P(10, 0, 1))) == 0
+    assert L.rt_owned_pixels(C.byref(P(10, 50, 1, band_rows=16, band_first=1, band_step=2))) == 180
+
+
+def test_ppm_bytes_match_reference_format():
+    """main.cpp:95-97,143-144: "P3\\n{nx} {ny}\\n255\\n" then "r g b\\n" per pixel."""
+    irgb = np.array([[[0, 1, 2], [255, 128, 7]], [[12, 34, 56], [-2147483648, 9, 100]]], dtype=np.int32)
+    want = "P3\n2 2\n255\n" + "".join(f"{p[0]} {p[1]} {p[2]}\n" for row in irgb for p in row)
+    assert R.format_ppm(irgb) == want.encode()
+    path = os.path.join(ROOT, "build", "test_out.ppm")
+    os.makedirs(os.path.dirname(path), exist_ok=True)
+    R.write_ppm(path, irgb)
+    assert open(path, "rb").read() == want.encode()
+
+
+def test_null_and_invalid_arguments_are_reported_not_fatal():
+    L = R.load_library()
+    assert L.rt_device_count(None) == -1
+    assert L.rt_create(0, None) == -1
+    assert L.rt_upload_scene(None, 1, None, None, None, None, None, None, None) == -1
+    assert L.rt_render_stats(None, None, None) == -1
+    assert b"null" in L.rt_last_error(None)
+    L.rt_destroy(None)
