@@ -1,0 +1,179 @@
+#!/usr/bin/env python3
+"""Throughput of the render loop on MI355X: Mrays/s on the 1200x800 RTOW final scene.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload c3|c1|c2|c5]
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+One step = one render of the whole image: each rank renders its interleaved row bands (scene and
+camera replicated, resident in HBM before the timed region) and, for N > 1, one RCCL gather
+assembles the rows on rank 0.  Total work is fixed as N grows ("strong" scaling).  Rank 0 prints
+one JSON line.
+"""
+import argparse
+import ctypes as C
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+import torch.distributed as dist
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+import raytracing_amd as R                                   # noqa: E402
+from raytracing_amd import dist as rdist                     # noqa: E402
+
+PEAK_FP32_VALU_TFLOPS = 157.3      # 256 CU x 4 SIMD x 32 lanes x 2 flop (FMA) x 2.4 GHz
+FLOP_PER_TEST = 18                 # oc (3) + oc.d (5) + oc.oc (5) + -r^2 (1) + b^2 (1) + a*c (1) + - (1) + compare (1)
+FLOP_PER_RAY_EXTRA = 150           # hit resolve + scatter, per closest-hit query
+
+WORKLOADS = {
+    # name: (scene, width, height, spp)
+    "c1": ("final", 1200, 800, 10),
+    "c2": ("three", 400, 225, 100),
+    "c3": ("final", 1200, 800, 500),
+    "c4": ("final", 3840, 2160, 1024),
+}
+
+
+def cpu_baseline(width, height, spp):
+    """The reference's own compiled render code (oracle/_ref, built from /root/reference by
+    oracle/Makefile) on one host core, on a bounded band of the same workload.  Falls back to the
+    C port of the oracle when the reference build is not present."""
+    rows = 40
+    j0 = height // 2 - rows // 2
+    ref = os.path.join(ROOT, "oracle", "_ref", "libref_render.so")
+    if os.path.exists(ref):
+        L = C.CDLL(ref)
+        L.ref_render_rows.restype = C.c_uint64
+        L.ref_render_rows.argtypes = [C.c_char_p, C.c_int, C.c_int, C.c_int, C.c_uint, C.c_int, C.c_int, C.POINTER(C.c_float)]
+        t0 = time.perf_counter()
+        rays = L.ref_render_rows(b"final", width, height, spp, 1, j0, j0 + rows, None)
+        dt = time.perf_counter() - t0
+        kind = "reference"
+    else:
+        sys.path.insert(0, os.path.join(ROOT, "tests"))
+        import _oracle as O
+        scene = O.SceneArrays.from_table(R.final_scene_table())
+        cam = O.final_camera(width, height)
+        t0 = time.perf_counter()
+        _, _, rays = O.render(scene, cam, width, height, spp, O.usrc_philox(0), j0, j0 + rows, fast=True)
+        dt = time.perf_counter() - t0
+        kind = "port"
+    return {"value": rays / dt / 1e6, "unit": "Mrays/s", "cores": 1, "kind": kind,
+            "sample": f"rows {j0}..{j0 + rows} of {width}x{height}, {spp} spp, final scene: {rays} rays in {dt:.1f} s",
+            "samples_per_s": rows * width * spp / dt}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--workload", default="c3", choices=sorted(WORKLOADS))
+    ap.add_argument("--spp", type=int, default=0, help="override samples per pixel")
+    ap.add_argument("--band-rows", type=int, default=8)
+    ap.add_argument("--seed", type=int, default=0)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {args.gpus}")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU: the render path has no CPU fallback")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        dist.init_process_group("nccl", device_id=dev)
+
+    scene_name, width, height, spp = WORKLOADS[args.workload]
+    if args.spp:
+        spp = args.spp
+    rt = R.Renderer(local_rank)
+    if scene_name == "final":
+        table = R.final_scene_table()
+        rt.upload_scene(table)
+        rt.set_camera(R.final_camera(width, height))
+    else:
+        table = R.three_sphere_table()
+        rt.upload_scene(table)
+        rt.set_camera(R.three_camera(width, height))
+    n_spheres = len(table)
+
+    band = args.band_rows
+    p = rt.params(width, height, spp, seed=args.seed, band_rows=band, band_first=rank, band_step=world)
+    pad = rdist.max_owned_rows(height, band, world)
+    out = torch.zeros((pad, width, 3), dtype=torch.int32, device=dev)
+    idx = rdist.row_index(height, band, world, dev) if world > 1 else None
+    stream = torch.cuda.current_stream().cuda_stream
+
+    kernel_ms, rays_per_step = [], []
+
+    def step(record):
+        rt.render_device(p, d_irgb=out.data_ptr(), stream=stream)
+        img = rdist.gather_rows(out, height, band, rank, world, src_index=idx)
+        rays, ms = rt.stats()                 # waits for this rank's kernels (HIP events on `stream`)
+        if record:
+            kernel_ms.append(ms)
+            rays_per_step.append(rays)
+        return img
+
+    for _ in range(args.warmup):
+        step(False)
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        img = step(True)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    elapsed = time.perf_counter() - t0
+
+    t = torch.tensor([elapsed, float(sum(rays_per_step)), float(np.mean(kernel_ms)), float(np.max(kernel_ms))], dtype=torch.float64, device=dev)
+    if world > 1:
+        tmax = t.clone(); dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        tsum = t.clone(); dist.all_reduce(tsum, op=dist.ReduceOp.SUM)
+        elapsed, total_rays, kms_mean, kms_max = tmax[0].item(), tsum[1].item(), tsum[2].item() / world, tmax[3].item()
+    else:
+        elapsed, total_rays, kms_mean, kms_max = t[0].item(), t[1].item(), t[2].item(), t[3].item()
+
+    if rank == 0:
+        samples = width * height * spp * args.steps
+        value = total_rays / elapsed / 1e6
+        flop_per_ray = FLOP_PER_TEST * n_spheres + FLOP_PER_RAY_EXTRA
+        # dominant kernel = the render megakernel; per-launch algorithmic flops of THIS rank's launch / its mean duration
+        my_rays = float(np.mean(rays_per_step))
+        achieved = my_rays * flop_per_ray / (float(np.mean(kernel_ms)) * 1e-3) / 1e12
+        line = {
+            "metric": "Mrays/s (1200x800 RTOW final scene)", "value": value, "unit": "Mrays/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3,
+            "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": f"{args.workload}: RTOW final random-spheres scene ({n_spheres} spheres), {width}x{height}, {spp} spp, max depth 50"
+                       if scene_name == "final" else f"{args.workload}: three-sphere material scene, {width}x{height}, {spp} spp",
+                       "band_rows": band, "partition": f"interleaved row bands over {world} GPU(s), one RCCL gather to rank 0" if world > 1 else "single GPU",
+                       "seed": args.seed, "mode": "megakernel"},
+            "msamples_per_s": samples / elapsed / 1e6, "rays_per_sample": total_rays / samples,
+            "kernel_ms_mean": kms_mean, "kernel_ms_max": kms_max,
+            "roofline": {"bound": "valu", "achieved": achieved, "peak": PEAK_FP32_VALU_TFLOPS, "unit": "TFLOP/s",
+                         "frac": achieved / PEAK_FP32_VALU_TFLOPS, "traffic": None,
+                         "kernel": "k_render_mega", "flop_per_ray": flop_per_ray,
+                         "note": "FP32 vector-ALU bound (HBM traffic and MFMA are not on this path); algorithmic flops = rays x (18 x spheres + 150)"},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            line["cpu_baseline"] = cpu_baseline(1200, 800, 10)
+        checksum = int(img.to(torch.int64).sum().item()) if img is not None else None
+        line["image_checksum"] = checksum
+        print(json.dumps(line), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

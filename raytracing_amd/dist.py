@@ -1,0 +1,53 @@
+"""Row-band partition of one image over ranks and the single gather that reassembles it.
+
+Every (pixel, sample) is independent and the scene and camera are replicated, so the only
+exchange step of the path is the gather of finished rows to rank 0.  Bands are dealt round-robin
+(band b -> rank b mod world) so that cheap sky rows and expensive sphere rows spread evenly.
+Works on CUDA tensors over RCCL (backend "nccl") and on CPU tensors over gloo.
+"""
+import torch
+import torch.distributed as dist
+
+
+def owned_bands(height, band_rows, rank, world):
+    """[(y0, y1), ...] image-row ranges (from the top) that `rank` renders, in increasing y."""
+    nb = (height + band_rows - 1) // band_rows
+    return [(b * band_rows, min((b + 1) * band_rows, height)) for b in range(rank, nb, world)]
+
+
+def owned_row_count(height, band_rows, rank, world):
+    return sum(y1 - y0 for y0, y1 in owned_bands(height, band_rows, rank, world))
+
+
+def max_owned_rows(height, band_rows, world):
+    return max(owned_row_count(height, band_rows, r, world) for r in range(world))
+
+
+def row_index(height, band_rows, world, device=None):
+    """For the rank-major concatenation of padded per-rank buffers: index tensor `src` such that
+    image[y] = stacked[src[y]]."""
+    pad = max_owned_rows(height, band_rows, world)
+    src = torch.empty(height, dtype=torch.long)
+    for r in range(world):
+        k = 0
+        for y0, y1 in owned_bands(height, band_rows, r, world):
+            src[y0:y1] = torch.arange(r * pad + k, r * pad + k + (y1 - y0))
+            k += y1 - y0
+    return src.to(device) if device is not None else src
+
+
+def gather_rows(local, height, band_rows, rank, world, group=None, src_index=None):
+    """local: [max_owned_rows, width, C] tensor whose first owned_row_count rows are valid.
+    Returns the assembled [height, width, C] image on rank 0 and None elsewhere."""
+    if world == 1:
+        return local[:height]
+    pad = max_owned_rows(height, band_rows, world)
+    assert local.shape[0] == pad, (local.shape, pad)
+    if rank == 0:
+        parts = [torch.empty_like(local) for _ in range(world)]
+        dist.gather(local, parts, dst=0, group=group)
+        stacked = torch.cat(parts, dim=0)
+        idx = src_index if src_index is not None else row_index(height, band_rows, world, local.device)
+        return stacked.index_select(0, idx)
+    dist.gather(local, None, dst=0, group=group)
+    return None
