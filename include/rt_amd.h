@@ -35,8 +35,11 @@ enum rt_material { RT_LAMBERTIAN = 0, RT_METAL = 1, RT_DIELECTRIC = 2 };
 
 /* Kernel organisation for the bounce loop of Color() (main.cpp:13-39). */
 enum rt_mode {
-    RT_MODE_MEGAKERNEL = 0,   /* one lane per pixel, samples regenerated in-lane, scene in LDS */
-    RT_MODE_WAVEFRONT = 1     /* ray queues in HBM compacted with wave ballot/prefix counts */
+    RT_MODE_MEGAKERNEL = 0,   /* persistent waves; a lane whose path ends takes the next (pixel, sample)
+                                 item at once (ballot + prefix count); conservative FMA filter over the
+                                 spheres, exact test on the survivors */
+    RT_MODE_WAVEFRONT = 1,    /* ray queues in HBM compacted with wave ballot/prefix counts */
+    RT_MODE_PIXEL = 2         /* plain kernel: one lane per pixel, literal per-sphere test, scene in LDS */
 };
 
 /* The eight public fields of Camera (camera.h:13-21), copied one to one. */

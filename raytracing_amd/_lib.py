@@ -7,7 +7,7 @@ import numpy as np
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "librt_amd.so")
 
-MODE_MEGAKERNEL, MODE_WAVEFRONT = 0, 1
+MODE_MEGAKERNEL, MODE_WAVEFRONT, MODE_PIXEL = 0, 1, 2
 LAMBERTIAN, METAL, DIELECTRIC = 0, 1, 2
 
 # every symbol include/rt_amd.h declares

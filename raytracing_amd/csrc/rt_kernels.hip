@@ -34,6 +34,11 @@ static constexpr int kLdsBytesPerSphere = 40;
 static constexpr int kMaxLdsSpheres = 1536; // 60 KB of LDS per block -> at least two blocks per CU
 
 // Compact owned row r -> image row y (from the top).
+__device__ __forceinline__ int owned_row_to_y2(int band_rows, int band_first, int band_step, int r)
+{
+    const int k = r / band_rows;
+    return (band_first + k * band_step) * band_rows + (r - k * band_rows);
+}
 __device__ __forceinline__ int owned_row_to_y(const RenderArgs& a, int r)
 {
     const int k = r / a.band_rows;
@@ -152,6 +157,229 @@ __global__ void __launch_bounds__(kBlock) k_render_mega(const RenderArgs a)
     if (threadIdx.x == 0 && s_rays) atomicAdd(a.ray_counter, s_rays);
 }
 
+// ============================================================================ persistent megakernel
+// Work item = one sample of one pixel.  Items are numbered sample-major over 8x8 pixel tiles,
+//   item = s_rel * Q + q,   q = tile * 64 + (row_in_tile * 8 + col_in_tile),
+// so the 64 items a fresh wave picks up are one tile at one sample (coherent primary rays) and
+// both this kernel's stores and the resolve kernel's loads of the sample buffer are coalesced.
+// A wave draws items from a chunk it reserves with one atomic on a global counter; whenever a
+// lane's path ends it is handed the next item (ballot + prefix count), so every trip of the main
+// loop runs one closest-hit sweep with all lanes busy until the work runs out.
+//
+// The sweep is split in two:
+//   filter  (hot, 8 FMAs + 1 bit op per ray-sphere pair, branch-free, scene records in SGPRs or
+//            LDS): a conservative sign test of the discriminant, expanded about the world origin,
+//            with a per-sphere and per-ray slack that dominates every rounding error of both this
+//            form and the reference's.  The sign bits of 32 spheres are shifted into one register.
+//   exact   (cold): the few spheres whose bit says "maybe" are evaluated with the reference's own
+//            unfused arithmetic (sphere.cpp:15-52) in ascending index order with the shrinking
+//            upper bound of hittablelist.cpp:13-31, so the chosen sphere and t are bit-identical.
+struct TraceArgs {
+    const float4* frec;      // filter records (cx, cy, cz, |c|^2 - r^2 - slack), padded to a multiple of 32
+    const float4* geom; const float4* mat; const Aux* aux; int n, n_pad;
+    CameraD cam;
+    int width, height, max_depth; float tmin;
+    uint32_t k0, k1;
+    int band_rows, band_first, band_step, owned_rows;
+    int tiles_x; uint32_t Q;              // padded pixel count = tiles * 64
+    int s_begin, s_count;                 // sample batch
+    uint32_t total_items;                 // Q * s_count  (< 2^31)
+    float* samples;                       // [total_items][3]
+    unsigned long long* ray_counter;
+    unsigned int* work_counter;
+};
+
+static constexpr int kChunkItems = 512;
+static constexpr float kRaySlack = 512.0f * 5.9604645e-08f;   // relative slack on |o|^2 (2^-24 units)
+
+template <bool kLds>
+__global__ void __launch_bounds__(kBlock, 2) k_trace(const TraceArgs a)
+{
+    extern __shared__ float4 smem[];
+    // LDS: [geom n][mat n][aux n (8 B)] when kLds, then the per-wave hit stacks.
+    float4* s_geom = smem;
+    float4* s_mat = smem + (kLds ? a.n : 0);
+    Aux* s_aux = reinterpret_cast<Aux*>(smem + (kLds ? 2 * a.n : 0));
+    uint16_t* s_stack_base = reinterpret_cast<uint16_t*>(reinterpret_cast<char*>(smem) + (kLds ? (size_t)a.n * kLdsBytesPerSphere : 0));
+    if (kLds) {
+        for (int i = threadIdx.x; i < a.n; i += kBlock) { s_geom[i] = a.geom[i]; s_mat[i] = a.mat[i]; s_aux[i] = a.aux[i]; }
+    }
+    __syncthreads();
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    uint16_t* stack = s_stack_base + (size_t)wave * RT_MAX_DEPTH * 64 + lane;     // element k at stack[k * 64]
+
+    KeyedUniforms U; U.k0 = a.k0; U.k1 = a.k1; U.slot(0, 0, 0);
+    RayD ray; ray.o = mk(0, 0, 0); ray.d = mk(0, 0, 1);
+    int depth = 0; uint32_t item = 0, pix = 0, smp = 0;
+    bool active = false;
+    uint32_t rays = 0;
+    uint32_t pool_next = 0, pool_end = 0;      // wave-uniform
+    bool exhausted = false;                    // wave-uniform
+    const float fnx = (float)a.width, fny = (float)a.height;
+
+    for (;;) {
+        // ---------------------------------------------------------------- hand out new items
+        unsigned long long need = __ballot(!active);
+        while (need != 0ull && !(exhausted && pool_next == pool_end)) {
+            if (pool_next == pool_end) {
+                unsigned int g = 0;
+                if (lane == 0) g = atomicAdd(a.work_counter, (unsigned int)kChunkItems);
+                g = __builtin_amdgcn_readfirstlane(g);
+                if (g >= a.total_items) { exhausted = true; break; }
+                pool_next = g;
+                pool_end = (a.total_items - g < (uint32_t)kChunkItems) ? a.total_items : g + kChunkItems;
+            }
+            const uint32_t avail = pool_end - pool_next;
+            const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(need >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)need, 0u));
+            const uint32_t want = (uint32_t)__popcll(need);
+            if (!active && rank < avail) {
+                item = pool_next + rank;
+                const uint32_t s_rel = item / a.Q, q = item - s_rel * a.Q;
+                const uint32_t tile = q >> 6, l = q & 63u;
+                const int ty = (int)(tile / (uint32_t)a.tiles_x), tx = (int)(tile - (uint32_t)ty * (uint32_t)a.tiles_x);
+                const int i = tx * 8 + (int)(l & 7u), r = ty * 8 + (int)(l >> 3);
+                const int y = owned_row_to_y2(a.band_rows, a.band_first, a.band_step, r < a.owned_rows ? r : 0);
+                if (i < a.width && r < a.owned_rows && y < a.height) {
+                    const int j = a.height - 1 - y;
+                    pix = (uint32_t)j * (uint32_t)a.width + (uint32_t)i;
+                    smp = (uint32_t)a.s_begin + s_rel;
+                    U.slot(pix, smp, 0);
+                    const float ju = U.f(), jv = U.f();
+                    const float fu = (float)((double)i + (double)ju) / fnx;
+                    const float fv = (float)((double)j + (double)jv) / fny;
+                    float dx = 0.0f, dy = 0.0f;
+                    if (a.cam.lens_radius > 0.0f) {
+                        uint32_t grp = 1;
+                        do {
+                            const U4 w = philox4x32_10(pix, smp, 0, grp, a.k0, a.k1);
+                            dx = 2.0f * u01(w.x) - 1.0f; dy = 2.0f * u01(w.y) - 1.0f; ++grp;
+                        } while ((dx * dx) + (dy * dy) + 0.0f >= 1.0f);
+                    }
+                    ray = get_ray(a.cam, fu, fv, dx, dy);
+                    depth = 0;
+                    active = true;
+                } else {
+                    // padding pixel of an edge tile: its sample slot is never read
+                }
+            }
+            pool_next += (want < avail ? want : avail);
+            need = __ballot(!active);
+            // padding pixels leave their lane idle; they are re-served next trip, which is harmless
+            if (want <= avail) break;
+        }
+        if (!__any(active)) {
+            if (exhausted && pool_next == pool_end) break;
+            continue;
+        }
+
+        if (active) {
+            // ------------------------------------------------------------ filter + exact sweep
+            const float qa = dot(ray.d, ray.d);
+            const float oo = fmaf(ray.o.x, ray.o.x, fmaf(ray.o.y, ray.o.y, ray.o.z * ray.o.z));
+            const float nod = -fmaf(ray.o.x, ray.d.x, fmaf(ray.o.y, ray.d.y, ray.o.z * ray.d.z));
+            const float m2ox = -2.0f * ray.o.x, m2oy = -2.0f * ray.o.y, m2oz = -2.0f * ray.o.z;
+            const float fa = fmaf(ray.d.x, ray.d.x, fmaf(ray.d.y, ray.d.y, ray.d.z * ray.d.z));
+            const float na = -fa;
+            const float P = na * (oo - kRaySlack * oo);
+            float closest = FLT_MAX; int hit = -1;
+            // Filter records are read through the constant address space: the index is wave-uniform,
+            // so each record arrives by scalar load in SGPRs and feeds the FMAs as a scalar operand.
+            typedef float f4v __attribute__((ext_vector_type(4)));
+            typedef const __attribute__((address_space(4))) f4v* ConstRec;
+            const ConstRec frec_k = (ConstRec)(a.frec);
+            for (int base = 0; base < a.n_pad; base += 32) {
+                uint32_t mask = 0u;
+#pragma unroll
+                for (int jj = 0; jj < 32; ++jj) {
+                    const f4v f = frec_k[base + jj];
+                    const float b = fmaf(f.x, ray.d.x, fmaf(f.y, ray.d.y, fmaf(f.z, ray.d.z, nod)));
+                    const float ct = fmaf(f.x, m2ox, fmaf(f.y, m2oy, fmaf(f.z, m2oz, f.w)));
+                    const float dsc = fmaf(b, b, fmaf(na, ct, P));
+                    mask = __builtin_amdgcn_alignbit(mask, __float_as_uint(dsc), 31);   // append sign bit
+                }
+                uint32_t cand = ~mask;      // bit 31 = sphere `base`, bit 0 = sphere base + 31
+                while (cand) {
+                    const int jj = __clz((int)cand);
+                    cand &= ~(0x80000000u >> jj);
+                    const int k = base + jj;
+                    if (k < a.n) {
+                        const float4 g = kLds ? s_geom[k] : a.geom[k];
+                        const V3 oc = ray.o - mk(g.x, g.y, g.z);
+                        const float b = dot(oc, ray.d);
+                        const float cc = dot(oc, oc) - g.w;
+                        const float desc = b * b - qa * cc;
+                        if (desc > 0.0f) {
+                            const float sq = sqrtf(desc);
+                            float temp = (-b - sq) / qa;
+                            if (!(temp < closest && temp > a.tmin)) temp = (-b + sq) / qa;
+                            if (temp < closest && temp > a.tmin) { closest = temp; hit = k; }
+                        }
+                    }
+                }
+            }
+            ++rays;
+            // ------------------------------------------------------------ shade (main.cpp:13-39)
+            V3 sample = mk(0.0f, 0.0f, 0.0f); bool done = true;
+            if (hit >= 0) {
+                const float4 g = kLds ? s_geom[hit] : a.geom[hit];
+                const float4 m = kLds ? s_mat[hit] : a.mat[hit];
+                const Aux x = kLds ? s_aux[hit] : a.aux[hit];
+                const V3 p = ray.o + closest * ray.d;
+                const V3 nrm = (p - mk(g.x, g.y, g.z)) / x.radius;
+                if (depth < a.max_depth) {
+                    V3 att; RayD out;
+                    U.slot(pix, smp, (uint32_t)depth + 1u);
+                    if (scatter(x.type, mk(m.x, m.y, m.z), m.w, ray, p, nrm, U, att, out)) {
+                        stack[depth * 64] = (uint16_t)hit; ++depth; ray = out; done = false;
+                    }
+                }
+            } else {
+                sample = sky(ray.d);
+                for (int k = depth - 1; k >= 0; --k) {
+                    const int h = stack[k * 64];
+                    const float4 m = kLds ? s_mat[h] : a.mat[h];
+                    sample = mk(m.x, m.y, m.z) * sample;
+                }
+            }
+            if (done) {
+                float* o = a.samples + (size_t)item * 3;
+                o[0] = sample.x; o[1] = sample.y; o[2] = sample.z;
+                active = false;
+            }
+        }
+    }
+    // one atomic per wave
+    for (int off = 32; off > 0; off >>= 1) rays += __shfl_down(rays, off);
+    if (lane == 0 && rays) atomicAdd(a.ray_counter, (unsigned long long)rays);
+}
+
+// Ordered per-pixel sum of a sample batch: col += sample for s ascending, exactly the
+// accumulation order of main.cpp:124-134; the last batch applies `col /= ns` and quantises.
+struct ResolveArgs {
+    const float* samples; float* accum;     // accum: [Q][3] running sums
+    uint32_t Q; int tiles_x; int s_count; int first, last;
+    int width, owned_rows, spp;
+    float* rgb_mean; int32_t* irgb;
+};
+__global__ void __launch_bounds__(256) k_resolve(const ResolveArgs a)
+{
+    const uint32_t q = blockIdx.x * 256u + threadIdx.x;
+    if (q >= a.Q) return;
+    V3 col = a.first ? mk(0.0f, 0.0f, 0.0f) : mk(a.accum[3 * (size_t)q], a.accum[3 * (size_t)q + 1], a.accum[3 * (size_t)q + 2]);
+    const uint32_t tile = q >> 6, l = q & 63u;
+    const int ty = (int)(tile / (uint32_t)a.tiles_x), tx = (int)(tile - (uint32_t)ty * (uint32_t)a.tiles_x);
+    const int i = tx * 8 + (int)(l & 7u), r = ty * 8 + (int)(l >> 3);
+    if (i >= a.width || r >= a.owned_rows) return;
+    const float* sp = a.samples + 3 * (size_t)q;
+    for (int s = 0; s < a.s_count; ++s, sp += 3 * (size_t)a.Q) col = col + mk(sp[0], sp[1], sp[2]);
+    if (!a.last) { a.accum[3 * (size_t)q] = col.x; a.accum[3 * (size_t)q + 1] = col.y; a.accum[3 * (size_t)q + 2] = col.z; return; }
+    const float inv = 1.0f / (float)a.spp;          // Vec3::operator/=(float), vec3.cpp:109-118
+    const float mr = col.x * inv, mg = col.y * inv, mb = col.z * inv;
+    const size_t o = ((size_t)r * a.width + i) * 3;
+    if (a.rgb_mean) { a.rgb_mean[o] = mr; a.rgb_mean[o + 1] = mg; a.rgb_mean[o + 2] = mb; }
+    if (a.irgb) { a.irgb[o] = quantise(mr); a.irgb[o + 1] = quantise(mg); a.irgb[o + 2] = quantise(mb); }
+}
+
 // ============================================================================ unit-level kernels
 __global__ void k_test_sphere_hit(int n, const float* ro, const float* rd, const float* c, const float* radius,
                                   const float* tmin, const float* tmax, int32_t* hit, float* t, float* p, float* nrm)
@@ -205,6 +433,11 @@ struct rt_context {
     int device = -1;
     std::string error;
     float4* d_geom = nullptr; float4* d_mat = nullptr; Aux* d_aux = nullptr; int n = 0;
+    float4* d_frec = nullptr; int n_pad = 0;
+    float* d_samples = nullptr; size_t samples_bytes = 0;      // sample buffer of the persistent megakernel
+    float* d_accum = nullptr; size_t accum_bytes = 0;          // running per-pixel sums across sample batches
+    unsigned int* d_work = nullptr;
+    int num_cu = 0; int trace_blocks_per_cu[2] = { 0, 0 };
     bool have_camera = false; CameraD cam{};
     unsigned long long* d_rays = nullptr;
     hipEvent_t ev0 = nullptr, ev1 = nullptr; hipStream_t last_stream = nullptr; bool pending = false;
@@ -238,7 +471,7 @@ static bool params_ok(const rt_params* p)
 {
     return p && p->width > 0 && p->height > 0 && p->spp > 0 && p->max_depth >= 0 && p->max_depth <= RT_MAX_DEPTH &&
            p->band_rows > 0 && p->band_first >= 0 && p->band_step > 0 &&
-           (p->mode == RT_MODE_MEGAKERNEL || p->mode == RT_MODE_WAVEFRONT);
+           (p->mode == RT_MODE_MEGAKERNEL || p->mode == RT_MODE_WAVEFRONT || p->mode == RT_MODE_PIXEL);
 }
 
 namespace {
@@ -275,6 +508,8 @@ int rt_create(int device_ordinal, rt_context** out)
     ctx->device = device_ordinal;
     hipError_t e = hipSetDevice(device_ordinal);
     if (e == hipSuccess) e = hipMalloc(&ctx->d_rays, sizeof(unsigned long long));
+    if (e == hipSuccess) e = hipMalloc(&ctx->d_work, sizeof(unsigned int));
+    if (e == hipSuccess) { hipDeviceProp_t prop; e = hipGetDeviceProperties(&prop, device_ordinal); if (e == hipSuccess) ctx->num_cu = prop.multiProcessorCount; }
     if (e == hipSuccess) e = hipEventCreate(&ctx->ev0);
     if (e == hipSuccess) e = hipEventCreate(&ctx->ev1);
     if (e != hipSuccess) { fail(nullptr, RT_ERR_HIP, "rt_create: %s", hipGetErrorString(e)); rt_destroy(ctx); return RT_ERR_HIP; }
@@ -288,6 +523,7 @@ void rt_destroy(rt_context* ctx)
     (void)hipSetDevice(ctx->device);
     if (ctx->pending) (void)hipStreamSynchronize(ctx->last_stream);
     (void)hipFree(ctx->d_geom); (void)hipFree(ctx->d_mat); (void)hipFree(ctx->d_aux); (void)hipFree(ctx->d_rays);
+    (void)hipFree(ctx->d_frec); (void)hipFree(ctx->d_samples); (void)hipFree(ctx->d_accum); (void)hipFree(ctx->d_work);
     if (ctx->ev0) (void)hipEventDestroy(ctx->ev0);
     if (ctx->ev1) (void)hipEventDestroy(ctx->ev1);
     delete ctx;
@@ -302,6 +538,19 @@ int rt_upload_scene(rt_context* ctx, int n, const float* cx, const float* cy, co
     if (n <= 0 || !cx || !cy || !cz || !radius || !material || !albedo_rgb || !param) return fail(ctx, RT_ERR_INVALID, "rt_upload_scene: null array or n <= 0");
     if (n > 65535) return fail(ctx, RT_ERR_TOO_LARGE, "rt_upload_scene: %d spheres exceeds the 65535 limit of the 16-bit hit stack", n);
     std::vector<float4> geom(n), mat(n); std::vector<Aux> aux(n);
+    const int n_pad = (n + 31) / 32 * 32;
+    // Filter records.  The filter evaluates b^2 - a*(|c|^2 - r^2 - 2 o.c + |o|^2) with FMAs; its
+    // rounding error and the reference's are each below 32 ulp(1) * a * ((|o|+|c|)^2 + r^2), so a
+    // slack of 256 * 2^-24 * (|c|^2 + r^2) per sphere plus 512 * 2^-24 * |o|^2 per ray (applied in
+    // the kernel) makes "filter negative" imply "reference discriminant not positive".
+    std::vector<float4> frec(n_pad, make_float4(0.0f, 0.0f, 0.0f, FLT_MAX));
+    for (int i = 0; i < n; ++i) {
+        const double cc = (double)cx[i] * cx[i] + (double)cy[i] * cy[i] + (double)cz[i] * cz[i], rr = (double)radius[i] * radius[i];
+        const double k = cc - rr - 256.0 * 5.9604644775390625e-08 * (cc + rr);
+        float kf = (float)k;
+        if ((double)kf > k) kf = nextafterf(kf, -INFINITY);
+        frec[i] = make_float4(cx[i], cy[i], cz[i], kf);
+    }
     for (int i = 0; i < n; ++i) {
         if (material[i] < RT_LAMBERTIAN || material[i] > RT_DIELECTRIC) return fail(ctx, RT_ERR_INVALID, "rt_upload_scene: sphere %d has unknown material %d", i, material[i]);
         geom[i] = make_float4(cx[i], cy[i], cz[i], radius[i] * radius[i]);
@@ -311,8 +560,11 @@ int rt_upload_scene(rt_context* ctx, int n, const float* cx, const float* cy, co
     }
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     if (ctx->pending) { HIP_TRY(ctx, hipStreamSynchronize(ctx->last_stream)); ctx->pending = false; }
-    (void)hipFree(ctx->d_geom); (void)hipFree(ctx->d_mat); (void)hipFree(ctx->d_aux);
-    ctx->d_geom = nullptr; ctx->d_mat = nullptr; ctx->d_aux = nullptr; ctx->n = 0;
+    (void)hipFree(ctx->d_geom); (void)hipFree(ctx->d_mat); (void)hipFree(ctx->d_aux); (void)hipFree(ctx->d_frec);
+    ctx->d_geom = nullptr; ctx->d_mat = nullptr; ctx->d_aux = nullptr; ctx->d_frec = nullptr; ctx->n = 0;
+    HIP_TRY(ctx, hipMalloc(&ctx->d_frec, sizeof(float4) * n_pad));
+    HIP_TRY(ctx, hipMemcpy(ctx->d_frec, frec.data(), sizeof(float4) * n_pad, hipMemcpyHostToDevice));
+    ctx->n_pad = n_pad;
     HIP_TRY(ctx, hipMalloc(&ctx->d_geom, sizeof(float4) * n));
     HIP_TRY(ctx, hipMalloc(&ctx->d_mat, sizeof(float4) * n));
     HIP_TRY(ctx, hipMalloc(&ctx->d_aux, sizeof(Aux) * n));
@@ -356,7 +608,8 @@ int rt_render_device(rt_context* ctx, const rt_params* p, float* d_rgb_mean, int
     hipStream_t st = static_cast<hipStream_t>(stream);
     const int owned = (int)rt_owned_rows(p);
     HIP_TRY(ctx, hipMemsetAsync(ctx->d_rays, 0, sizeof(unsigned long long), st));
-    if (owned > 0) {
+    HIP_TRY(ctx, hipEventRecord(ctx->ev0, st));
+    if (owned > 0 && p->mode == RT_MODE_PIXEL) {
         RenderArgs a;
         a.geom = ctx->d_geom; a.mat = ctx->d_mat; a.aux = ctx->d_aux; a.n = ctx->n; a.cam = ctx->cam;
         a.width = p->width; a.height = p->height; a.spp = p->spp; a.max_depth = p->max_depth; a.tmin = p->tmin;
@@ -364,18 +617,64 @@ int rt_render_device(rt_context* ctx, const rt_params* p, float* d_rgb_mean, int
         a.band_rows = p->band_rows; a.band_first = p->band_first; a.band_step = p->band_step; a.owned_rows = owned;
         a.rgb_mean = d_rgb_mean; a.irgb = d_irgb; a.ray_counter = ctx->d_rays;
         const dim3 grid((p->width + 15) / 16, (owned + 15) / 16), block(kBlock);
-        HIP_TRY(ctx, hipEventRecord(ctx->ev0, st));
-        if (ctx->n <= kMaxLdsSpheres) {
-            hipLaunchKernelGGL(k_render_mega<true>, grid, block, (size_t)ctx->n * kLdsBytesPerSphere, st, a);
-        } else {
-            hipLaunchKernelGGL(k_render_mega<false>, grid, block, 0, st, a);
-        }
+        if (ctx->n <= kMaxLdsSpheres) hipLaunchKernelGGL(k_render_mega<true>, grid, block, (size_t)ctx->n * kLdsBytesPerSphere, st, a);
+        else hipLaunchKernelGGL(k_render_mega<false>, grid, block, 0, st, a);
         HIP_TRY(ctx, hipGetLastError());
-        HIP_TRY(ctx, hipEventRecord(ctx->ev1, st));
-    } else {
-        HIP_TRY(ctx, hipEventRecord(ctx->ev0, st));
-        HIP_TRY(ctx, hipEventRecord(ctx->ev1, st));
+    } else if (owned > 0) {
+        const int tiles_x = (p->width + 7) / 8, tiles_y = (owned + 7) / 8;
+        const uint64_t Q = (uint64_t)tiles_x * tiles_y * 64;
+        // sample batches: the per-batch sample buffer stays below 4 GiB and item ids below 2^31
+        uint64_t per_batch = (4ull << 30) / (Q * 12);
+        if (per_batch > (1ull << 31) / Q) per_batch = (1ull << 31) / Q;
+        if (per_batch == 0) return fail(ctx, RT_ERR_TOO_LARGE, "rt_render_device: %llu pixels in one call exceed the sample-buffer limit; split the image into bands", (unsigned long long)Q);
+        const int batches = (int)((p->spp + per_batch - 1) / per_batch);
+        const int s_per = (p->spp + batches - 1) / batches;
+        const size_t need = (size_t)Q * s_per * 12;
+        if (ctx->samples_bytes < need) {
+            HIP_TRY(ctx, hipStreamSynchronize(st));
+            (void)hipFree(ctx->d_samples); ctx->d_samples = nullptr; ctx->samples_bytes = 0;
+            HIP_TRY(ctx, hipMalloc(&ctx->d_samples, need)); ctx->samples_bytes = need;
+        }
+        if (batches > 1 && ctx->accum_bytes < Q * 12) {
+            HIP_TRY(ctx, hipStreamSynchronize(st));
+            (void)hipFree(ctx->d_accum); ctx->d_accum = nullptr; ctx->accum_bytes = 0;
+            HIP_TRY(ctx, hipMalloc(&ctx->d_accum, Q * 12)); ctx->accum_bytes = Q * 12;
+        }
+        const bool lds = ctx->n <= kMaxLdsSpheres;
+        const size_t shmem = (lds ? (size_t)ctx->n * kLdsBytesPerSphere : 0) + (size_t)(kBlock / 64) * RT_MAX_DEPTH * 64 * sizeof(uint16_t);
+        int& bpc = ctx->trace_blocks_per_cu[lds ? 1 : 0];
+        if (bpc == 0) {
+            int nb = 0;
+            hipError_t e = lds ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_trace<true>, kBlock, shmem)
+                               : hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_trace<false>, kBlock, shmem);
+            if (e != hipSuccess || nb <= 0) nb = 1;
+            bpc = nb;
+        }
+        for (int bi = 0, s0 = 0; bi < batches; ++bi, s0 += s_per) {
+            const int sc = (p->spp - s0 < s_per) ? p->spp - s0 : s_per;
+            TraceArgs a;
+            a.frec = ctx->d_frec; a.geom = ctx->d_geom; a.mat = ctx->d_mat; a.aux = ctx->d_aux; a.n = ctx->n; a.n_pad = ctx->n_pad; a.cam = ctx->cam;
+            a.width = p->width; a.height = p->height; a.max_depth = p->max_depth; a.tmin = p->tmin;
+            a.k0 = (uint32_t)p->seed; a.k1 = (uint32_t)(p->seed >> 32);
+            a.band_rows = p->band_rows; a.band_first = p->band_first; a.band_step = p->band_step; a.owned_rows = owned;
+            a.tiles_x = tiles_x; a.Q = (uint32_t)Q; a.s_begin = s0; a.s_count = sc; a.total_items = (uint32_t)(Q * sc);
+            a.samples = ctx->d_samples; a.ray_counter = ctx->d_rays; a.work_counter = ctx->d_work;
+            HIP_TRY(ctx, hipMemsetAsync(ctx->d_work, 0, sizeof(unsigned int), st));
+            uint64_t want_blocks = ((uint64_t)a.total_items + kChunkItems * 4 - 1) / (kChunkItems * 4);
+            const uint64_t cap_blocks = (uint64_t)ctx->num_cu * bpc;
+            const dim3 grid((unsigned)(want_blocks < cap_blocks ? want_blocks : cap_blocks)), block(kBlock);
+            if (lds) hipLaunchKernelGGL(k_trace<true>, grid, block, shmem, st, a);
+            else hipLaunchKernelGGL(k_trace<false>, grid, block, shmem, st, a);
+            HIP_TRY(ctx, hipGetLastError());
+            ResolveArgs r;
+            r.samples = ctx->d_samples; r.accum = ctx->d_accum; r.Q = (uint32_t)Q; r.tiles_x = tiles_x; r.s_count = sc;
+            r.first = (bi == 0); r.last = (bi == batches - 1); r.width = p->width; r.owned_rows = owned; r.spp = p->spp;
+            r.rgb_mean = d_rgb_mean; r.irgb = d_irgb;
+            hipLaunchKernelGGL(k_resolve, dim3((unsigned)((Q + 255) / 256)), dim3(256), 0, st, r);
+            HIP_TRY(ctx, hipGetLastError());
+        }
     }
+    HIP_TRY(ctx, hipEventRecord(ctx->ev1, st));
     ctx->last_stream = st; ctx->pending = true;
     return RT_OK;
 }

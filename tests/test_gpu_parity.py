@@ -132,14 +132,15 @@ def _setup(rt, m):
         rt.set_camera(R.three_camera(m["nx"], m["ny"]))
 
 
+@pytest.mark.parametrize("mode", [R.MODE_MEGAKERNEL, R.MODE_PIXEL])
 @pytest.mark.parametrize("name", ["philox_final_96x64x4", "philox_final_40x30x16_ap0",
                                   "philox_three_hollow_80x45x8", "philox_three_64x36x32"])
-def test_render_is_bit_identical_to_reference_image(rt, name):
+def test_render_is_bit_identical_to_reference_image(rt, name, mode):
     """Images written by the reference's own Color()/Sphere/Material code on the keyed stream."""
     m = _meta()[name]
     want = np.load(os.path.join(G, f"img_{name}.npy"))
     _setup(rt, m)
-    rgb, irgb, rays, ms = rt.render(rt.params(m["nx"], m["ny"], m["ns"], seed=m["seed"]))
+    rgb, irgb, rays, ms = rt.render(rt.params(m["nx"], m["ny"], m["ns"], seed=m["seed"], mode=mode))
     assert rays == m["rays"]
     assert mismatch(rgb, want) == 0
     q = np.zeros_like(irgb)
