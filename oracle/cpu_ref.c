@@ -68,9 +68,9 @@ double orc_uniform(orc_usrc *u)
     } else if (u->kind == 1) {
         k = (int)random();
     } else {
-        uint32_t ctr[4] = { u->px, u->smp, u->bounce, u->draw / 3u }, key[2] = { (uint32_t)u->seed, (uint32_t)(u->seed >> 32) }, out[4];
+        uint32_t ctr[4] = { u->px, u->smp, u->bounce, u->draw / 4u }, key[2] = { (uint32_t)u->seed, (uint32_t)(u->seed >> 32) }, out[4];
         orc_philox4x32_10(ctr, key, out);
-        k = (int)((out[u->draw % 3u] >> 8) << 7);
+        k = (int)((out[u->draw % 4u] >> 8) << 7);
         u->draw += 1;
     }
     u->consumed += 1;
@@ -254,14 +254,18 @@ uint64_t orc_render(const orc_scene *s, const orc_camera *cam, int nx, int ny, i
                 float fv = (float)(j + orc_uniform(u)) / (float)ny;
                 float dx = 0.0f, dy = 0.0f;
                 if (cam->lens_radius > 0.0f) {
-                    /* RandomUnitInDisk (camera.cpp:31-44).  Keyed source: groups 1.. of slot
-                     * (pixel, sample, 0).  Other sources: a private splitmix stream, because the
+                    /* RandomUnitInDisk (camera.cpp:31-44).  Keyed source: try 0 is words 2,3 of group 0
+                     * of slot (pixel, sample, 0); try t >= 1 is words 0,1 (t odd) or 2,3 (t even) of
+                     * group (t + 1) / 2.  Other sources: a private splitmix stream, because the
                      * reference's lens generator is seeded from std::random_device (unpinned). */
-                    uint32_t grp = 1;
+                    uint32_t t = 0;
                     do {
                         float a, b;
-                        if (u->kind == 2) { a = orc_usrc_word(u, grp, 0); b = orc_usrc_word(u, grp, 1); ++grp; }
-                        else {
+                        if (u->kind == 2) {
+                            int hi = (t == 0) || ((t & 1u) == 0);
+                            uint32_t grp = (t + 1u) >> 1;
+                            a = orc_usrc_word(u, grp, hi ? 2 : 0); b = orc_usrc_word(u, grp, hi ? 3 : 1); ++t;
+                        } else {
                             uint64_t z = (lens_state += 0x9E3779B97F4A7C15ull);
                             z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull; z = (z ^ (z >> 27)) * 0x94D049BB133111EBull; z ^= z >> 31;
                             a = (float)(uint32_t)(z >> 40) * (1.0f / 16777216.0f); b = (float)((uint32_t)z >> 8) * (1.0f / 16777216.0f);

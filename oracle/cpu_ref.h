@@ -22,8 +22,8 @@ typedef struct {
 typedef struct { orc_vec3 origin, llc, horiz, vert, u, v, w; float lens_radius; } orc_camera;
 
 /* Uniform source.  kind 0: replay of recorded rand() integers; kind 1: glibc random() stream;
- * kind 2: Philox4x32-10 keyed on (pixel, sample, bounce): draw d of a slot is word d%3 of
- * group d/3; value = (word >> 8) / 2^24. */
+ * kind 2: Philox4x32-10 keyed on (pixel, sample, bounce): draw d of a slot is word d%4 of
+ * group d/4; value = (word >> 8) / 2^24. */
 typedef struct {
     int kind;
     const int *replay; long n_replay; long pos;

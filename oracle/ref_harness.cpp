@@ -33,8 +33,7 @@ static size_t g_inject_pos = 0;
 static bool g_logging = false;
 static std::vector<int> g_log;
 // Philox key state (RAND_PHILOX): one slot = (pixel, sample, bounce); draw d of a slot is
-// word d%3 of group d/3 (RandomInUnitSphere draws 3 per rejection iteration; every other
-// consumer draws fewer than 3 per slot).
+// word d%4 of group d/4.
 static uint32_t g_px = 0, g_smp = 0, g_bounce = 0, g_draw = 0;
 static uint64_t g_seed = 0;
 
@@ -45,10 +44,10 @@ extern "C" int rand(void) noexcept
         if (g_inject_pos >= g_inject.size()) { fprintf(stderr, "inject underflow\n"); abort(); }
         v = g_inject[g_inject_pos++];
     } else if (g_mode == RAND_PHILOX) {
-        uint32_t ctr[4] = { g_px, g_smp, g_bounce, g_draw / 3u }, out[4];
+        uint32_t ctr[4] = { g_px, g_smp, g_bounce, g_draw / 4u }, out[4];
         uint32_t key[2] = { (uint32_t)g_seed, (uint32_t)(g_seed >> 32) };
         orc_philox4x32_10(ctr, key, out);
-        v = (int)((out[g_draw % 3u] >> 8) << 7);   // (x>>8)/2^24 == v/2^31 exactly
+        v = (int)((out[g_draw % 4u] >> 8) << 7);   // (x>>8)/2^24 == v/2^31 exactly
         ++g_draw;
     } else {
         v = (int)random();
@@ -290,7 +289,7 @@ static void gen_paths(const char* path, int n)
 // mode "libc":   the loop of main.cpp:118-141 as written there (rand() jitter, Camera::GetRay with
 //                its own lens RNG), glibc stream seeded `seed` after the scene is built.
 // mode "philox": same loop, every uniform taken from the keyed Philox stream.  The lens sample is
-//                drawn from slot (pixel, sample, 0) groups 1.. and applied with the expression of
+//                drawn from slot (pixel, sample, 0) (words named in the loop below) and applied with the expression of
 //                camera.cpp:48-52 on the reference Camera's public fields, because the reference's
 //                own lens generator (camera.cpp:33-35) cannot be seeded.
 struct RenderOut { std::vector<float> rgb; uint64_t rays; };
@@ -320,8 +319,12 @@ static RenderOut render(const std::string& scene, int nx, int ny, int ns, const 
                     float u = float(i + (std::rand() / (RAND_MAX + 1.0))) / float(nx);
                     float v = float(j + (std::rand() / (RAND_MAX + 1.0))) / float(ny);
                     if (cam.m_fLensRadius > 0.0f) {
-                        Vec3 p; uint32_t grp = 1;
-                        do { p = 2.0f * Vec3(philox_word(px, s, 0, grp, 0), philox_word(px, s, 0, grp, 1), 0.0f) - Vec3(1.0f, 1.0f, 0.0f); ++grp; } while (Dot(p, p) >= 1.0f);
+                        // lens try t: words 2,3 of group 0 for t = 0, then words 0,1 (t odd) / 2,3 (t even) of group (t+1)/2
+                        Vec3 p; uint32_t t = 0;
+                        do {
+                            const bool hi = (t == 0) || ((t & 1u) == 0); const uint32_t grp = (t + 1u) >> 1;
+                            p = 2.0f * Vec3(philox_word(px, s, 0, grp, hi ? 2 : 0), philox_word(px, s, 0, grp, hi ? 3 : 1), 0.0f) - Vec3(1.0f, 1.0f, 0.0f); ++t;
+                        } while (Dot(p, p) >= 1.0f);
                         Vec3 rd = cam.m_fLensRadius * p;
                         Vec3 offset = cam.m_oU * rd.GetX() + cam.m_oV * rd.GetY();
                         ray = Ray(cam.m_oOrigin + offset, cam.m_oLowerLeftCorner + u * cam.m_oHorizontal + v * cam.m_oVertical - cam.m_oOrigin - offset);

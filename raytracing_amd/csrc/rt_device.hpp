@@ -46,22 +46,26 @@ __device__ __forceinline__ U4 philox4x32_10(uint32_t c0, uint32_t c1, uint32_t c
 __device__ __forceinline__ float u01(uint32_t w) { return (float)(w >> 8) * (1.0f / 16777216.0f); }
 
 // Uniform providers.  f() is `static_cast<float>(rand()/(RAND_MAX+1.0))`, d() the double itself.
-// Keyed provider: draw d of the current slot is word d%3 of group d/3.
+// Keyed provider: draw d of the current slot is word d%4 of group d/4 (all four words of a Philox
+// block are consumed before the next block is computed).
 struct KeyedUniforms {
     uint32_t px, smp, bounce, k0, k1, draw; U4 cur;
     __device__ __forceinline__ void slot(uint32_t p, uint32_t s, uint32_t b) { px = p; smp = s; bounce = b; draw = 0; }
+    // Computes group 0 of the current slot ahead of its first use (lets divergent consumers share it).
+    __device__ __forceinline__ void prefetch() { cur = philox4x32_10(px, smp, bounce, 0u, k0, k1); }
     __device__ __forceinline__ float f()
     {
-        const uint32_t w = draw % 3u;
-        if (w == 0) cur = philox4x32_10(px, smp, bounce, draw / 3u, k0, k1);
+        const uint32_t w = draw & 3u;
+        if (w == 0 && draw != 0) cur = philox4x32_10(px, smp, bounce, draw >> 2, k0, k1);
         ++draw;
-        return u01(w == 0 ? cur.x : (w == 1 ? cur.y : cur.z));
+        return u01(w == 0 ? cur.x : (w == 1 ? cur.y : (w == 2 ? cur.z : cur.w)));
     }
     __device__ __forceinline__ double d() { return (double)f(); }
 };
 // Replay provider for the unit-level entry points: recorded rand() integers.
 struct ReplayUniforms {
     const int32_t* draws; int pos;
+    __device__ __forceinline__ void prefetch() {}
     __device__ __forceinline__ double d() { return (double)draws[pos++] / 2147483648.0; }
     __device__ __forceinline__ float f() { return (float)d(); }
 };
@@ -121,21 +125,24 @@ __device__ __forceinline__ V3 random_in_unit_sphere(U& u)
     return p;
 }
 
-// Material::Scatter for the three materials.  `param` = fuzz | ref_idx.
+// Material::Scatter for the three materials.  `param` = fuzz | ref_idx.  Lambertian and Metal both
+// draw one RandomInUnitSphere() and nothing else, so the rejection loop is shared by the lanes of
+// either kind; the arithmetic that follows is the reference's, material by material.
 template <class U>
 __device__ __forceinline__ bool scatter(int type, V3 albedo, float param, const RayD& in, V3 p, V3 n, U& u, V3& att, RayD& out)
 {
     out.o = p;
-    if (type == 0) {
-        const V3 target = (p + n) + random_in_unit_sphere(u);
-        out.d = target - p;
+    u.prefetch();
+    if (type != 2) {
+        const V3 rnd = random_in_unit_sphere(u);
         att = albedo;
-        return true;
-    }
-    if (type == 1) {
+        if (type == 0) {
+            const V3 target = (p + n) + rnd;
+            out.d = target - p;
+            return true;
+        }
         const V3 reflected = reflect(unit(in.d), n);
-        out.d = reflected + param * random_in_unit_sphere(u);
-        att = albedo;
+        out.d = reflected + param * rnd;
         return dot(out.d, n) > 0;
     }
     const V3 reflected = reflect(in.d, n);
@@ -157,6 +164,15 @@ __device__ __forceinline__ bool scatter(int type, V3 albedo, float param, const 
     else reflect_prob = 1.0f;
     out.d = (u.d() < (double)reflect_prob) ? reflected : refracted;
     return true;
+}
+
+// Lens sample t = 0, 1, 2, ... of slot (pixel, sample, 0) (RandomUnitInDisk's rejection loop,
+// camera.cpp:31-44): try 0 is words 2,3 of group 0 (whose words 0,1 are the pixel jitter); try
+// t >= 1 is words 0,1 (t odd) or 2,3 (t even) of group (t + 1) / 2.
+__device__ __forceinline__ void lens_words(const U4& blk, uint32_t t, float& a, float& b)
+{
+    const bool hi = (t == 0) || ((t & 1u) == 0);
+    a = u01(hi ? blk.z : blk.x); b = u01(hi ? blk.w : blk.y);
 }
 
 // ---------------------------------------------------------------------------- Camera::GetRay

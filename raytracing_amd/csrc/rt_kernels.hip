@@ -45,6 +45,28 @@ __device__ __forceinline__ int owned_row_to_y(const RenderArgs& a, int r)
     return (a.band_first + k * a.band_step) * a.band_rows + (r - k * a.band_rows);
 }
 
+// Camera ray of (pixel, sample): jitter from words 0,1 of group 0 (main.cpp:126-127), lens sample by
+// rejection from the words lens_words() names, then Camera::GetRay (camera.cpp:46-53).
+__device__ __forceinline__ RayD camera_ray(const CameraD& cam, uint32_t pix, uint32_t smp, int i, int j, float fnx, float fny, uint32_t k0, uint32_t k1)
+{
+    U4 blk = philox4x32_10(pix, smp, 0u, 0u, k0, k1);
+    const float fu = (float)((double)i + (double)u01(blk.x)) / fnx;
+    const float fv = (float)((double)j + (double)u01(blk.y)) / fny;
+    float dx = 0.0f, dy = 0.0f;
+    if (cam.lens_radius > 0.0f) {
+        uint32_t t = 0;
+        for (;;) {
+            float a, b;
+            lens_words(blk, t, a, b);
+            dx = 2.0f * a - 1.0f; dy = 2.0f * b - 1.0f;
+            if (!((dx * dx) + (dy * dy) + 0.0f >= 1.0f)) break;
+            ++t;
+            if (t & 1u) blk = philox4x32_10(pix, smp, 0u, (t + 1u) >> 1, k0, k1);
+        }
+    }
+    return get_ray(cam, fu, fv, dx, dy);
+}
+
 // ============================================================================ megakernel
 // One lane per pixel.  A lane walks its pixel's samples in order and, within a sample, the
 // bounces of Color() (main.cpp:13-39) iteratively; when a path ends the lane starts its next
@@ -82,23 +104,8 @@ __global__ void __launch_bounds__(kBlock) k_render_mega(const RenderArgs a)
         RayD ray; int depth = 0; int smp = 0;
         const float fnx = (float)a.width, fny = (float)a.height;
 
-        auto camera_ray = [&](int s) {
-            U.slot(pix, (uint32_t)s, 0);
-            const float ju = U.f(), jv = U.f();
-            const float fu = (float)((double)i + (double)ju) / fnx;
-            const float fv = (float)((double)j + (double)jv) / fny;
-            float dx = 0.0f, dy = 0.0f;
-            if (a.cam.lens_radius > 0.0f) {
-                uint32_t grp = 1;
-                do {
-                    const U4 w = philox4x32_10(pix, (uint32_t)s, 0, grp, a.k0, a.k1);
-                    dx = 2.0f * u01(w.x) - 1.0f; dy = 2.0f * u01(w.y) - 1.0f; ++grp;
-                } while ((dx * dx) + (dy * dy) + 0.0f >= 1.0f);
-            }
-            ray = get_ray(a.cam, fu, fv, dx, dy);
-            depth = 0;
-        };
-        camera_ray(0);
+        auto next_camera_ray = [&](int s) { ray = camera_ray(a.cam, pix, (uint32_t)s, i, j, fnx, fny, a.k0, a.k1); depth = 0; };
+        next_camera_ray(0);
 
         while (smp < a.spp) {
             // ---- HittableList::Hit (hittablelist.cpp:13-31) over Sphere::Hit (sphere.cpp:15-52)
@@ -143,7 +150,7 @@ __global__ void __launch_bounds__(kBlock) k_render_mega(const RenderArgs a)
             if (done) {
                 col = col + sample;
                 ++smp;
-                if (smp < a.spp) camera_ray(smp);
+                if (smp < a.spp) next_camera_ray(smp);
             }
         }
         const float inv = 1.0f / (float)a.spp;          // Vec3::operator/=(float), vec3.cpp:109-118
@@ -187,26 +194,34 @@ struct TraceArgs {
     float* samples;                       // [total_items][3]
     unsigned long long* ray_counter;
     unsigned int* work_counter;
+    uint16_t* stacks; uint32_t stack_stride;   // hit-index stacks in HBM: entry k of lane g at stacks[k * stack_stride + g]
 };
 
 static constexpr int kChunkItems = 512;
-static constexpr float kRaySlack = 512.0f * 5.9604645e-08f;   // relative slack on |o|^2 (2^-24 units)
+static constexpr int kCandSlots = 24;                           // candidate-list entries per lane (overflow flushes early)
+static constexpr float kRaySlack = 160.0f * 5.9604645e-08f;   // per-ray slack, relative to |o|^2
 
 template <bool kLds>
-__global__ void __launch_bounds__(kBlock, 2) k_trace(const TraceArgs a)
+__global__ void __launch_bounds__(kBlock) k_trace(const TraceArgs a)
 {
     extern __shared__ float4 smem[];
-    // LDS: [geom n][mat n][aux n (8 B)] when kLds, then the per-wave hit stacks.
+    // LDS: [geom n][mat n][aux n (8 B)] when kLds.
     float4* s_geom = smem;
     float4* s_mat = smem + (kLds ? a.n : 0);
     Aux* s_aux = reinterpret_cast<Aux*>(smem + (kLds ? 2 * a.n : 0));
-    uint16_t* s_stack_base = reinterpret_cast<uint16_t*>(reinterpret_cast<char*>(smem) + (kLds ? (size_t)a.n * kLdsBytesPerSphere : 0));
     if (kLds) {
         for (int i = threadIdx.x; i < a.n; i += kBlock) { s_geom[i] = a.geom[i]; s_mat[i] = a.mat[i]; s_aux[i] = a.aux[i]; }
     }
     __syncthreads();
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    uint16_t* stack = s_stack_base + (size_t)wave * RT_MAX_DEPTH * 64 + lane;     // element k at stack[k * 64]
+    // Per-lane candidate list: slot c of lane l at cand_list[c * 64] (2-byte entries, lanes contiguous).
+    uint16_t* cand_list = reinterpret_cast<uint16_t*>(reinterpret_cast<char*>(smem) + (kLds ? (size_t)a.n * kLdsBytesPerSphere : 0)) + (size_t)wave * kCandSlots * 64 + lane;
+    // The recursion's attenuation chain is replayed innermost-first when a path reaches the sky, so
+    // each lane keeps the indices of the spheres it bounced off.  One 2-byte store per bounce and a
+    // short read-back per finished path: kept in HBM so that LDS does not limit occupancy.
+    uint16_t* stack = a.stacks + (size_t)blockIdx.x * kBlock + threadIdx.x;
+    const size_t sstride = a.stack_stride;
+    (void)wave;
 
     KeyedUniforms U; U.k0 = a.k0; U.k1 = a.k1; U.slot(0, 0, 0);
     RayD ray; ray.o = mk(0, 0, 0); ray.d = mk(0, 0, 1);
@@ -243,19 +258,7 @@ __global__ void __launch_bounds__(kBlock, 2) k_trace(const TraceArgs a)
                     const int j = a.height - 1 - y;
                     pix = (uint32_t)j * (uint32_t)a.width + (uint32_t)i;
                     smp = (uint32_t)a.s_begin + s_rel;
-                    U.slot(pix, smp, 0);
-                    const float ju = U.f(), jv = U.f();
-                    const float fu = (float)((double)i + (double)ju) / fnx;
-                    const float fv = (float)((double)j + (double)jv) / fny;
-                    float dx = 0.0f, dy = 0.0f;
-                    if (a.cam.lens_radius > 0.0f) {
-                        uint32_t grp = 1;
-                        do {
-                            const U4 w = philox4x32_10(pix, smp, 0, grp, a.k0, a.k1);
-                            dx = 2.0f * u01(w.x) - 1.0f; dy = 2.0f * u01(w.y) - 1.0f; ++grp;
-                        } while ((dx * dx) + (dy * dy) + 0.0f >= 1.0f);
-                    }
-                    ray = get_ray(a.cam, fu, fv, dx, dy);
+                    ray = camera_ray(a.cam, pix, smp, i, j, fnx, fny, a.k0, a.k1);
                     depth = 0;
                     active = true;
                 } else {
@@ -273,29 +276,57 @@ __global__ void __launch_bounds__(kBlock, 2) k_trace(const TraceArgs a)
         }
 
         if (active) {
-            // ------------------------------------------------------------ filter + exact sweep
+            // ------------------------------------------------------------ filter
+            // Per ray: unit direction (approximate is enough for a conservative test), -(o.d^), 2o,
+            // -|o|^2 (1 - slack).  Per sphere record (cx, cy, cz, k), k = |c|^2 - r^2 - slack_i:
+            //   b = c.d^ - o.d^            3 FMA      w = 2 o.c - |o|^2'        3 FMA
+            //   e = b*b + w                1 FMA      s = e - k                 1 SUB   -> sign bit
+            // s >= 0 is necessary for the reference's discriminant to be positive.
             const float qa = dot(ray.d, ray.d);
+            const float rs = __frsqrt_rn(fmaf(ray.d.x, ray.d.x, fmaf(ray.d.y, ray.d.y, ray.d.z * ray.d.z)));
+            const float hx = ray.d.x * rs, hy = ray.d.y * rs, hz = ray.d.z * rs;
+            const float nod = -fmaf(ray.o.x, hx, fmaf(ray.o.y, hy, ray.o.z * hz));
+            const float p2x = 2.0f * ray.o.x, p2y = 2.0f * ray.o.y, p2z = 2.0f * ray.o.z;
             const float oo = fmaf(ray.o.x, ray.o.x, fmaf(ray.o.y, ray.o.y, ray.o.z * ray.o.z));
-            const float nod = -fmaf(ray.o.x, ray.d.x, fmaf(ray.o.y, ray.d.y, ray.o.z * ray.d.z));
-            const float m2ox = -2.0f * ray.o.x, m2oy = -2.0f * ray.o.y, m2oz = -2.0f * ray.o.z;
-            const float fa = fmaf(ray.d.x, ray.d.x, fmaf(ray.d.y, ray.d.y, ray.d.z * ray.d.z));
-            const float na = -fa;
-            const float P = na * (oo - kRaySlack * oo);
+            const float noo = kRaySlack * oo - oo;
             float closest = FLT_MAX; int hit = -1;
             // Filter records are read through the constant address space: the index is wave-uniform,
             // so each record arrives by scalar load in SGPRs and feeds the FMAs as a scalar operand.
             typedef float f4v __attribute__((ext_vector_type(4)));
             typedef const __attribute__((address_space(4))) f4v* ConstRec;
             const ConstRec frec_k = (ConstRec)(a.frec);
+            int cnt = 0;
+
+            // Exact test of the listed candidates, ascending index, shrinking upper bound: the
+            // arithmetic of sphere.cpp:15-52 / hittablelist.cpp:21-29, unfused.
+            auto flush = [&]() {
+                for (int c = 0; c < cnt; ++c) {
+                    const int k = cand_list[c * 64];
+                    const float4 g = kLds ? s_geom[k] : a.geom[k];
+                    const V3 oc = ray.o - mk(g.x, g.y, g.z);
+                    const float b = dot(oc, ray.d);
+                    const float cc = dot(oc, oc) - g.w;
+                    const float desc = b * b - qa * cc;
+                    if (desc > 0.0f) {
+                        const float sq = sqrtf(desc);
+                        float temp = (-b - sq) / qa;
+                        if (!(temp < closest && temp > a.tmin)) temp = (-b + sq) / qa;
+                        if (temp < closest && temp > a.tmin) { closest = temp; hit = k; }
+                    }
+                }
+                cnt = 0;
+            };
+
             for (int base = 0; base < a.n_pad; base += 32) {
                 uint32_t mask = 0u;
 #pragma unroll
                 for (int jj = 0; jj < 32; ++jj) {
                     const f4v f = frec_k[base + jj];
-                    const float b = fmaf(f.x, ray.d.x, fmaf(f.y, ray.d.y, fmaf(f.z, ray.d.z, nod)));
-                    const float ct = fmaf(f.x, m2ox, fmaf(f.y, m2oy, fmaf(f.z, m2oz, f.w)));
-                    const float dsc = fmaf(b, b, fmaf(na, ct, P));
-                    mask = __builtin_amdgcn_alignbit(mask, __float_as_uint(dsc), 31);   // append sign bit
+                    const float b = fmaf(f.x, hx, fmaf(f.y, hy, fmaf(f.z, hz, nod)));
+                    const float w = fmaf(f.x, p2x, fmaf(f.y, p2y, fmaf(f.z, p2z, noo)));
+                    const float e = fmaf(b, b, w);
+                    const float sgn = e - f.w;
+                    mask = __builtin_amdgcn_alignbit(mask, __float_as_uint(sgn), 31);   // append sign bit
                 }
                 uint32_t cand = ~mask;      // bit 31 = sphere `base`, bit 0 = sphere base + 31
                 while (cand) {
@@ -303,20 +334,12 @@ __global__ void __launch_bounds__(kBlock, 2) k_trace(const TraceArgs a)
                     cand &= ~(0x80000000u >> jj);
                     const int k = base + jj;
                     if (k < a.n) {
-                        const float4 g = kLds ? s_geom[k] : a.geom[k];
-                        const V3 oc = ray.o - mk(g.x, g.y, g.z);
-                        const float b = dot(oc, ray.d);
-                        const float cc = dot(oc, oc) - g.w;
-                        const float desc = b * b - qa * cc;
-                        if (desc > 0.0f) {
-                            const float sq = sqrtf(desc);
-                            float temp = (-b - sq) / qa;
-                            if (!(temp < closest && temp > a.tmin)) temp = (-b + sq) / qa;
-                            if (temp < closest && temp > a.tmin) { closest = temp; hit = k; }
-                        }
+                        if (cnt == kCandSlots) flush();
+                        cand_list[cnt * 64] = (uint16_t)k; ++cnt;
                     }
                 }
             }
+            flush();
             ++rays;
             // ------------------------------------------------------------ shade (main.cpp:13-39)
             V3 sample = mk(0.0f, 0.0f, 0.0f); bool done = true;
@@ -330,13 +353,13 @@ __global__ void __launch_bounds__(kBlock, 2) k_trace(const TraceArgs a)
                     V3 att; RayD out;
                     U.slot(pix, smp, (uint32_t)depth + 1u);
                     if (scatter(x.type, mk(m.x, m.y, m.z), m.w, ray, p, nrm, U, att, out)) {
-                        stack[depth * 64] = (uint16_t)hit; ++depth; ray = out; done = false;
+                        stack[(size_t)depth * sstride] = (uint16_t)hit; ++depth; ray = out; done = false;
                     }
                 }
             } else {
                 sample = sky(ray.d);
                 for (int k = depth - 1; k >= 0; --k) {
-                    const int h = stack[k * 64];
+                    const int h = stack[(size_t)k * sstride];
                     const float4 m = kLds ? s_mat[h] : a.mat[h];
                     sample = mk(m.x, m.y, m.z) * sample;
                 }
@@ -437,6 +460,7 @@ struct rt_context {
     float* d_samples = nullptr; size_t samples_bytes = 0;      // sample buffer of the persistent megakernel
     float* d_accum = nullptr; size_t accum_bytes = 0;          // running per-pixel sums across sample batches
     unsigned int* d_work = nullptr;
+    uint16_t* d_stacks = nullptr; size_t stacks_lanes = 0;
     int num_cu = 0; int trace_blocks_per_cu[2] = { 0, 0 };
     bool have_camera = false; CameraD cam{};
     unsigned long long* d_rays = nullptr;
@@ -523,7 +547,7 @@ void rt_destroy(rt_context* ctx)
     (void)hipSetDevice(ctx->device);
     if (ctx->pending) (void)hipStreamSynchronize(ctx->last_stream);
     (void)hipFree(ctx->d_geom); (void)hipFree(ctx->d_mat); (void)hipFree(ctx->d_aux); (void)hipFree(ctx->d_rays);
-    (void)hipFree(ctx->d_frec); (void)hipFree(ctx->d_samples); (void)hipFree(ctx->d_accum); (void)hipFree(ctx->d_work);
+    (void)hipFree(ctx->d_frec); (void)hipFree(ctx->d_samples); (void)hipFree(ctx->d_accum); (void)hipFree(ctx->d_work); (void)hipFree(ctx->d_stacks);
     if (ctx->ev0) (void)hipEventDestroy(ctx->ev0);
     if (ctx->ev1) (void)hipEventDestroy(ctx->ev1);
     delete ctx;
@@ -539,14 +563,15 @@ int rt_upload_scene(rt_context* ctx, int n, const float* cx, const float* cy, co
     if (n > 65535) return fail(ctx, RT_ERR_TOO_LARGE, "rt_upload_scene: %d spheres exceeds the 65535 limit of the 16-bit hit stack", n);
     std::vector<float4> geom(n), mat(n); std::vector<Aux> aux(n);
     const int n_pad = (n + 31) / 32 * 32;
-    // Filter records.  The filter evaluates b^2 - a*(|c|^2 - r^2 - 2 o.c + |o|^2) with FMAs; its
-    // rounding error and the reference's are each below 32 ulp(1) * a * ((|o|+|c|)^2 + r^2), so a
-    // slack of 256 * 2^-24 * (|c|^2 + r^2) per sphere plus 512 * 2^-24 * |o|^2 per ray (applied in
-    // the kernel) makes "filter negative" imply "reference discriminant not positive".
+    // Filter records (cx, cy, cz, k), k = |c|^2 - r^2 - slack_i.  With u = 2^-24, M = |o| + |c| and the
+    // ray direction normalised, the filter's own rounding error is below 32 u M^2 and the reference's
+    // discriminant (divided by |d|^2) is off by less than 32 u (|o - c|^2 + r^2); since
+    // M^2 <= 2 (|o|^2 + |c|^2), slack_i = 160 u |c|^2 + 48 u r^2 here plus 160 u |o|^2 per ray in the
+    // kernel makes "filter negative" imply "reference discriminant not positive".
     std::vector<float4> frec(n_pad, make_float4(0.0f, 0.0f, 0.0f, FLT_MAX));
     for (int i = 0; i < n; ++i) {
         const double cc = (double)cx[i] * cx[i] + (double)cy[i] * cy[i] + (double)cz[i] * cz[i], rr = (double)radius[i] * radius[i];
-        const double k = cc - rr - 256.0 * 5.9604644775390625e-08 * (cc + rr);
+        const double k = cc - rr - 5.9604644775390625e-08 * (160.0 * cc + 48.0 * rr);
         float kf = (float)k;
         if ((double)kf > k) kf = nextafterf(kf, -INFINITY);
         frec[i] = make_float4(cx[i], cy[i], cz[i], kf);
@@ -641,7 +666,7 @@ int rt_render_device(rt_context* ctx, const rt_params* p, float* d_rgb_mean, int
             HIP_TRY(ctx, hipMalloc(&ctx->d_accum, Q * 12)); ctx->accum_bytes = Q * 12;
         }
         const bool lds = ctx->n <= kMaxLdsSpheres;
-        const size_t shmem = (lds ? (size_t)ctx->n * kLdsBytesPerSphere : 0) + (size_t)(kBlock / 64) * RT_MAX_DEPTH * 64 * sizeof(uint16_t);
+        const size_t shmem = (lds ? (size_t)ctx->n * kLdsBytesPerSphere : 0) + (size_t)(kBlock / 64) * kCandSlots * 64 * sizeof(uint16_t);
         int& bpc = ctx->trace_blocks_per_cu[lds ? 1 : 0];
         if (bpc == 0) {
             int nb = 0;
@@ -649,6 +674,12 @@ int rt_render_device(rt_context* ctx, const rt_params* p, float* d_rgb_mean, int
                                : hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_trace<false>, kBlock, shmem);
             if (e != hipSuccess || nb <= 0) nb = 1;
             bpc = nb;
+        }
+        const size_t lanes = (size_t)ctx->num_cu * bpc * kBlock;
+        if (ctx->stacks_lanes < lanes) {
+            HIP_TRY(ctx, hipStreamSynchronize(st));
+            (void)hipFree(ctx->d_stacks); ctx->d_stacks = nullptr; ctx->stacks_lanes = 0;
+            HIP_TRY(ctx, hipMalloc(&ctx->d_stacks, lanes * RT_MAX_DEPTH * sizeof(uint16_t))); ctx->stacks_lanes = lanes;
         }
         for (int bi = 0, s0 = 0; bi < batches; ++bi, s0 += s_per) {
             const int sc = (p->spp - s0 < s_per) ? p->spp - s0 : s_per;
@@ -659,6 +690,7 @@ int rt_render_device(rt_context* ctx, const rt_params* p, float* d_rgb_mean, int
             a.band_rows = p->band_rows; a.band_first = p->band_first; a.band_step = p->band_step; a.owned_rows = owned;
             a.tiles_x = tiles_x; a.Q = (uint32_t)Q; a.s_begin = s0; a.s_count = sc; a.total_items = (uint32_t)(Q * sc);
             a.samples = ctx->d_samples; a.ray_counter = ctx->d_rays; a.work_counter = ctx->d_work;
+            a.stacks = ctx->d_stacks; a.stack_stride = (uint32_t)ctx->stacks_lanes;
             HIP_TRY(ctx, hipMemsetAsync(ctx->d_work, 0, sizeof(unsigned int), st));
             uint64_t want_blocks = ((uint64_t)a.total_items + kChunkItems * 4 - 1) / (kChunkItems * 4);
             const uint64_t cap_blocks = (uint64_t)ctx->num_cu * bpc;
