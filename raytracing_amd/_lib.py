@@ -5,7 +5,8 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "librt_amd.so")
+# RT_AMD_LIB selects another build of the same ABI (diagnostic builds under tools/)
+LIB_PATH = os.environ.get("RT_AMD_LIB") or os.path.join(_HERE, "librt_amd.so")
 
 MODE_MEGAKERNEL, MODE_WAVEFRONT, MODE_PIXEL = 0, 1, 2
 LAMBERTIAN, METAL, DIELECTRIC = 0, 1, 2

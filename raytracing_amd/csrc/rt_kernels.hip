@@ -197,6 +197,15 @@ struct TraceArgs {
     uint16_t* stacks; uint32_t stack_stride;   // hit-index stacks in HBM: entry k of lane g at stacks[k * stack_stride + g]
 };
 
+// Diagnostic build (-DRT_SECTION_TIMERS): every wave accumulates s_memtime ticks per section of the
+// main loop into g_section_ticks.  Never enabled in the shipped library.
+#ifdef RT_SECTION_TIMERS
+__device__ unsigned long long g_section_ticks[8];
+#define SECTION_BEGIN() const unsigned long long t_sec0_ = __builtin_amdgcn_s_memtime()
+#define SECTION_MARK(idx) do { const unsigned long long t_now_ = __builtin_amdgcn_s_memtime(); sec_acc[idx] += t_now_ - t_last_; t_last_ = t_now_; } while (0)
+#else
+#define SECTION_MARK(idx) do { } while (0)
+#endif
 static constexpr int kChunkItems = 512;
 static constexpr int kCandSlots = 24;                           // candidate-list entries per lane (overflow flushes early)
 static constexpr float kRaySlack = 160.0f * 5.9604645e-08f;   // per-ray slack, relative to |o|^2
@@ -231,6 +240,10 @@ __global__ void __launch_bounds__(kBlock) k_trace(const TraceArgs a)
     uint32_t pool_next = 0, pool_end = 0;      // wave-uniform
     bool exhausted = false;                    // wave-uniform
     const float fnx = (float)a.width, fny = (float)a.height;
+#ifdef RT_SECTION_TIMERS
+    unsigned long long sec_acc[8] = { 0, 0, 0, 0, 0, 0, 0, 0 };
+    unsigned long long t_last_ = __builtin_amdgcn_s_memtime();
+#endif
 
     for (;;) {
         // ---------------------------------------------------------------- hand out new items
@@ -270,6 +283,7 @@ __global__ void __launch_bounds__(kBlock) k_trace(const TraceArgs a)
             // padding pixels leave their lane idle; they are re-served next trip, which is harmless
             if (want <= avail) break;
         }
+        SECTION_MARK(0);
         if (!__any(active)) {
             if (exhausted && pool_next == pool_end) break;
             continue;
@@ -317,6 +331,7 @@ __global__ void __launch_bounds__(kBlock) k_trace(const TraceArgs a)
                 cnt = 0;
             };
 
+            SECTION_MARK(1);
             for (int base = 0; base < a.n_pad; base += 32) {
                 uint32_t mask = 0u;
 #pragma unroll
@@ -328,6 +343,7 @@ __global__ void __launch_bounds__(kBlock) k_trace(const TraceArgs a)
                     const float sgn = e - f.w;
                     mask = __builtin_amdgcn_alignbit(mask, __float_as_uint(sgn), 31);   // append sign bit
                 }
+                SECTION_MARK(2);
                 uint32_t cand = ~mask;      // bit 31 = sphere `base`, bit 0 = sphere base + 31
                 while (cand) {
                     const int jj = __clz((int)cand);
@@ -338,8 +354,10 @@ __global__ void __launch_bounds__(kBlock) k_trace(const TraceArgs a)
                         cand_list[cnt * 64] = (uint16_t)k; ++cnt;
                     }
                 }
+                SECTION_MARK(3);
             }
             flush();
+            SECTION_MARK(4);
             ++rays;
             // ------------------------------------------------------------ shade (main.cpp:13-39)
             V3 sample = mk(0.0f, 0.0f, 0.0f); bool done = true;
@@ -349,6 +367,7 @@ __global__ void __launch_bounds__(kBlock) k_trace(const TraceArgs a)
                 const Aux x = kLds ? s_aux[hit] : a.aux[hit];
                 const V3 p = ray.o + closest * ray.d;
                 const V3 nrm = (p - mk(g.x, g.y, g.z)) / x.radius;
+                SECTION_MARK(5);
                 if (depth < a.max_depth) {
                     V3 att; RayD out;
                     U.slot(pix, smp, (uint32_t)depth + 1u);
@@ -356,6 +375,7 @@ __global__ void __launch_bounds__(kBlock) k_trace(const TraceArgs a)
                         stack[(size_t)depth * sstride] = (uint16_t)hit; ++depth; ray = out; done = false;
                     }
                 }
+                SECTION_MARK(6);
             } else {
                 sample = sky(ray.d);
                 for (int k = depth - 1; k >= 0; --k) {
@@ -369,8 +389,12 @@ __global__ void __launch_bounds__(kBlock) k_trace(const TraceArgs a)
                 o[0] = sample.x; o[1] = sample.y; o[2] = sample.z;
                 active = false;
             }
+            SECTION_MARK(7);
         }
     }
+#ifdef RT_SECTION_TIMERS
+    if (lane == 0) for (int k = 0; k < 8; ++k) atomicAdd(&g_section_ticks[k], sec_acc[k]);
+#endif
     // one atomic per wave
     for (int off = 32; off > 0; off >>= 1) rays += __shfl_down(rays, off);
     if (lane == 0 && rays) atomicAdd(a.ray_counter, (unsigned long long)rays);
@@ -507,6 +531,15 @@ struct DevBuf {
     template <class T> T* as() { return static_cast<T*>(p); }
 };
 }
+
+#ifdef RT_SECTION_TIMERS
+extern "C" int rt_debug_section_ticks(unsigned long long* out8, int reset)
+{
+    if (out8 && hipMemcpyFromSymbol(out8, HIP_SYMBOL(g_section_ticks), 8 * sizeof(unsigned long long)) != hipSuccess) return -3;
+    if (reset) { unsigned long long z[8] = { 0 }; if (hipMemcpyToSymbol(HIP_SYMBOL(g_section_ticks), z, sizeof z) != hipSuccess) return -3; }
+    return 0;
+}
+#endif
 
 extern "C" {
 

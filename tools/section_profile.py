@@ -1,0 +1,27 @@
+#!/usr/bin/env python3
+"""Where the wave time of k_trace goes: runs the diagnostic build (make -C raytracing_amd/csrc prof) and
+prints the share of s_memtime ticks per section of the main loop.  RT_AMD_LIB must point at it."""
+import ctypes as C
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+os.environ["RT_AMD_LIB"] = os.path.join(ROOT, "tools", "librt_amd_prof.so")
+sys.path.insert(0, ROOT)
+import raytracing_amd as R
+
+spp = int(sys.argv[1]) if len(sys.argv) > 1 else 50
+rt = R.Renderer(0)
+rt.upload_scene(R.final_scene_table())
+rt.set_camera(R.final_camera(1200, 800))
+L = R.load_library()
+buf = (C.c_ulonglong * 8)()
+L.rt_debug_section_ticks(buf, 1)
+rgb, irgb, rays, ms = rt.render(rt.params(1200, 800, spp, seed=0))
+L.rt_debug_section_ticks(buf, 0)
+names = ["regenerate", "ray setup", "filter", "append", "flush (exact)", "hit record", "scatter", "sky+store"]
+order = [0, 1, 2, 3, 4, 5, 6, 7]
+tot = sum(buf[i] for i in order)
+print(f"{rays} rays, kernel {ms:.2f} ms (timers add overhead)")
+for i in order:
+    print(f"{names[i]:>14s} {100.0 * buf[i] / tot:5.1f} %")
