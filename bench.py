@@ -35,6 +35,7 @@ WORKLOADS = {
     "c2": ("three", 400, 225, 100),
     "c3": ("final", 1200, 800, 500),
     "c4": ("final", 3840, 2160, 1024),
+    "c5": ("grid20k", 1920, 1080, 256),
 }
 
 
@@ -77,6 +78,8 @@ def main():
     ap.add_argument("--band-rows", type=int, default=8)
     ap.add_argument("--seed", type=int, default=0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--rehearse-on-one-gpu", action="store_true",
+                    help="debug: all ranks share GPU 0 and gather over gloo (RCCL refuses two ranks on one device)")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -86,10 +89,15 @@ def main():
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {args.gpus}")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the render path has no CPU fallback")
+    if args.rehearse_on_one_gpu:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     if world > 1:
-        dist.init_process_group("nccl", device_id=dev)
+        if args.rehearse_on_one_gpu:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=dev)
 
     scene_name, width, height, spp = WORKLOADS[args.workload]
     if args.spp:
@@ -97,6 +105,10 @@ def main():
     rt = R.Renderer(local_rank)
     if scene_name == "final":
         table = R.final_scene_table()
+        rt.upload_scene(table)
+        rt.set_camera(R.final_camera(width, height))
+    elif scene_name == "grid20k":
+        table = R.scene_grid(42, 75, 19996)
         rt.upload_scene(table)
         rt.set_camera(R.final_camera(width, height))
     else:
@@ -116,7 +128,10 @@ def main():
 
     def step(record):
         rt.render_device(p, d_irgb=out.data_ptr(), stream=stream)
-        img = rdist.gather_rows(out, height, band, rank, world, src_index=idx)
+        if args.rehearse_on_one_gpu and world > 1:
+            img = rdist.gather_rows(out.cpu(), height, band, rank, world, src_index=idx.cpu())
+        else:
+            img = rdist.gather_rows(out, height, band, rank, world, src_index=idx)
         rays, ms = rt.stats()                 # waits for this rank's kernels (HIP events on `stream`)
         if record:
             kernel_ms.append(ms)
@@ -138,6 +153,8 @@ def main():
 
     t = torch.tensor([elapsed, float(sum(rays_per_step)), float(np.mean(kernel_ms)), float(np.max(kernel_ms))], dtype=torch.float64, device=dev)
     if world > 1:
+        if args.rehearse_on_one_gpu:
+            t = t.cpu()
         tmax = t.clone(); dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         tsum = t.clone(); dist.all_reduce(tsum, op=dist.ReduceOp.SUM)
         elapsed, total_rays, kms_mean, kms_max = tmax[0].item(), tsum[1].item(), tsum[2].item() / world, tmax[3].item()
@@ -156,7 +173,8 @@ def main():
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3,
             "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": f"{args.workload}: RTOW final random-spheres scene ({n_spheres} spheres), {width}x{height}, {spp} spp, max depth 50"
-                       if scene_name == "final" else f"{args.workload}: three-sphere material scene, {width}x{height}, {spp} spp",
+                       if scene_name == "final" else (f"{args.workload}: synthetic {n_spheres}-sphere grid scene, {width}x{height}, {spp} spp, max depth 50"
+                                                      if scene_name == "grid20k" else f"{args.workload}: three-sphere material scene, {width}x{height}, {spp} spp"),
                        "band_rows": band, "partition": f"interleaved row bands over {world} GPU(s), one RCCL gather to rank 0" if world > 1 else "single GPU",
                        "seed": args.seed, "mode": "megakernel"},
             "msamples_per_s": samples / elapsed / 1e6, "rays_per_sample": total_rays / samples,

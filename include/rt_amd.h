@@ -112,6 +112,18 @@ int rt_render_stats(rt_context *ctx, uint64_t *rays, float *kernel_ms);
 int rt_render(rt_context *ctx, const rt_params *p, float *h_rgb_mean, int32_t *h_irgb,
               uint64_t *rays, float *kernel_ms);
 
+/* ---- scene setup helpers (host side, untimed) --------------------------------------------- */
+/* RandomScene() (main.cpp:41-83) generalised to a (2*half_extent)^2 grid of candidate cells with an
+ * explicit, compiler-independent draw order: candidate t = (a + half_extent) * 2*half_extent +
+ * (b + half_extent) takes Philox4x32-10 block (t, 0, 0, 0) under key `seed` as (choose_mat,
+ * jitter_x, jitter_z, -) and blocks (t, 1, 0, 0), (t, 2, 0, 0) for its material draws, each uniform
+ * being (word >> 8) * 2^-24.  Same ground sphere, 0.9 jitter, exclusion test around (4, 0.2, 0),
+ * 80 / 15 / 5 % material rule and three big spheres as the reference; at most max_small small
+ * spheres are kept (in candidate order).  half_extent = 11 gives the reference's 22 x 22 layout;
+ * half_extent = 75, max_small = 19996 gives the 20 000-sphere stress scene.  Writes rows of
+ * (cx cy cz radius material albedo_r albedo_g albedo_b param) into table9[cap][9]; *n_out = rows. */
+int rt_scene_grid(uint64_t seed, int half_extent, int max_small, float *table9, int cap, int *n_out);
+
 /* ---- output.ppm (main.cpp:91-97, 143-147) --------------------------------------------- */
 /* Formats "P3\n{w} {h}\n255\n" followed by one "r g b\n" line per pixel into buf.  Returns the
  * number of bytes written, or the required capacity (negated) when cap is too small. */

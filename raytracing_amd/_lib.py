@@ -14,7 +14,7 @@ LAMBERTIAN, METAL, DIELECTRIC = 0, 1, 2
 # every symbol include/rt_amd.h declares
 EXPORTS = ["rt_device_count", "rt_create", "rt_destroy", "rt_last_error", "rt_upload_scene", "rt_set_camera",
            "rt_owned_rows", "rt_owned_pixels", "rt_render_device", "rt_render_stats", "rt_render",
-           "rt_format_ppm", "rt_write_ppm", "rt_test_sphere_hit", "rt_test_scatter", "rt_test_get_ray",
+           "rt_scene_grid", "rt_format_ppm", "rt_write_ppm", "rt_test_sphere_hit", "rt_test_scatter", "rt_test_get_ray",
            "rt_test_philox"]
 
 
@@ -66,6 +66,7 @@ def load_library():
     L.rt_render_device.argtypes = [vp, C.POINTER(Params), vp, vp, vp]
     L.rt_render_stats.argtypes = [vp, C.POINTER(C.c_uint64), C.POINTER(C.c_float)]
     L.rt_render.argtypes = [vp, C.POINTER(Params), fp, ip, C.POINTER(C.c_uint64), C.POINTER(C.c_float)]
+    L.rt_scene_grid.argtypes = [C.c_uint64, C.c_int, C.c_int, fp, C.c_int, C.POINTER(C.c_int)]
     L.rt_format_ppm.argtypes = [ip, C.c_int, C.c_int, C.c_char_p, C.c_int64]
     L.rt_format_ppm.restype = C.c_int64
     L.rt_write_ppm.argtypes = [C.c_char_p, ip, C.c_int, C.c_int]
@@ -245,6 +246,18 @@ class Renderer:
         u32 = C.POINTER(C.c_uint32)
         self._check(self._L.rt_test_philox(self._ctx, n, c.ctypes.data_as(u32), k.ctypes.data_as(u32), out.ctypes.data_as(u32)))
         return out.reshape(n, 4)
+
+
+def scene_grid(seed=42, half_extent=75, max_small=19996):
+    """rt_scene_grid: RandomScene()'s rule on a (2*half_extent)^2 grid with an explicit Philox draw order."""
+    cap = (2 * half_extent) ** 2 + 4
+    table = np.zeros((cap, 9), dtype=np.float32)
+    n = C.c_int(0)
+    L = load_library()
+    rc = L.rt_scene_grid(seed, half_extent, max_small, _fp(table.reshape(-1)), cap, C.byref(n))
+    if rc != 0:
+        raise RtError(rc, L.rt_last_error(None).decode())
+    return table[:n.value].astype(np.float64)
 
 
 def format_ppm(irgb):

@@ -51,3 +51,16 @@ def gather_rows(local, height, band_rows, rank, world, group=None, src_index=Non
         return stacked.index_select(0, idx)
     dist.gather(local, None, dst=0, group=group)
     return None
+
+
+def render_image(rt, width, height, spp, seed=0, band_rows=8, rank=0, world=1, device=None, out=None, src_index=None,
+                 group=None, mode=0):
+    """Render this rank's bands with `rt` (a Renderer on this rank's GPU) into a device tensor and gather.
+    Returns (image on rank 0 | None, local tensor).  The kernels run on torch's current stream, so the
+    collective that follows is ordered after them."""
+    p = rt.params(width, height, spp, seed=seed, band_rows=band_rows, band_first=rank, band_step=world, mode=mode)
+    pad = max_owned_rows(height, band_rows, world)
+    if out is None:
+        out = torch.zeros((pad, width, 3), dtype=torch.int32, device=device)
+    rt.render_device(p, d_irgb=out.data_ptr(), stream=torch.cuda.current_stream().cuda_stream)
+    return gather_rows(out, height, band_rows, rank, world, group=group, src_index=src_index), out

@@ -62,3 +62,25 @@ def test_null_and_invalid_arguments_are_reported_not_fatal():
     assert L.rt_render_stats(None, None, None) == -1
     assert b"null" in L.rt_last_error(None)
     L.rt_destroy(None)
+
+
+def test_scene_grid_is_deterministic_and_follows_the_reference_rule():
+    """The 20 000-sphere stress scene: RandomScene()'s layout rule (main.cpp:41-83) on a 150 x 150 grid."""
+    t = R.scene_grid(42, 75, 19996)
+    assert t.shape == (20000, 9)
+    assert np.array_equal(t, R.scene_grid(42, 75, 19996))
+    assert not np.array_equal(t, R.scene_grid(43, 75, 19996))
+    assert tuple(t[0, :5]) == (0.0, -1000.0, 0.0, 1000.0, 0.0)
+    small = t[1:-3]
+    assert np.all(small[:, 3] == np.float32(0.2)) and np.all(small[:, 1] == np.float32(0.2))
+    frac = [np.mean(small[:, 4] == m) for m in (0, 1, 2)]
+    assert abs(frac[0] - 0.80) < 0.01 and abs(frac[1] - 0.15) < 0.01 and abs(frac[2] - 0.05) < 0.01
+    d = np.sqrt((small[:, 0] - 4.0) ** 2 + small[:, 2] ** 2)
+    assert d.min() > 0.9                                   # exclusion zone around (4, 0.2, 0)
+    cell = np.floor(small[:, [0, 2]])
+    jitter = small[:, [0, 2]] - cell
+    assert jitter.min() >= 0.0 and jitter.max() < 0.9 + 1e-6
+    assert np.all(small[small[:, 4] == 1, 8] < 0.5) and np.all(small[small[:, 4] == 2, 8] == 1.5)
+    assert [tuple(r[:5]) for r in t[-3:]] == [(0, 1, 0, 1, 2), (-4, 1, 0, 1, 0), (4, 1, 0, 1, 1)]
+    # the reference-sized layout: 22 x 22 cells
+    assert 470 <= len(R.scene_grid(1, 11, 10 ** 6)) <= 488

@@ -226,6 +226,31 @@ def test_full_size_properties(rt):
     assert not np.array_equal(a, c)
 
 
+def test_stress_scene_rows_match_oracle(rt):
+    """Config 5 (20 000 spheres, 1920x1080): scene records no longer fit LDS; rows against the oracle."""
+    table = R.scene_grid(42, 75, 19996)
+    assert len(table) == 20000
+    scene = O.SceneArrays.from_table(table)
+    ocam = O.final_camera(1920, 1080)
+    rt.upload_scene(table)
+    rt.set_camera(R.final_camera(1920, 1080))
+    # two image rows in the sphere field (y = 700, 701) = band 350 of 2-row bands, 1 sample
+    p = rt.params(1920, 1080, 1, seed=4, band_rows=2, band_first=350, band_step=10000)
+    rgb, irgb, rays, _ = rt.render(p)
+    want, wq, wrays = O.render(scene, ocam, 1920, 1080, 1, O.usrc_philox(4), 1080 - 702, 1080 - 700, fast=False)
+    assert rays == wrays and same(rgb, want) and np.array_equal(irgb, wq)
+    # a mid-size scene whose count is not a multiple of the filter's 32-sphere chunk
+    table = R.scene_grid(7, 20, 10 ** 6)
+    assert len(table) % 32 != 0 and len(table) > 1536
+    rt.upload_scene(table)
+    rt.set_camera(R.final_camera(96, 64))
+    rgb, irgb, rays, _ = rt.render(rt.params(96, 64, 2, seed=8))
+    want, wq, wrays = O.render(O.SceneArrays.from_table(table), O.final_camera(96, 64), 96, 64, 2, O.usrc_philox(8))
+    assert rays == wrays and same(rgb, want) and np.array_equal(irgb, wq)
+    both = [rt.render(rt.params(96, 64, 2, seed=8, mode=m))[0] for m in (R.MODE_MEGAKERNEL, R.MODE_PIXEL)]
+    assert same(both[0], both[1])
+
+
 def test_edge_cases(rt):
     rt.upload_scene(R.three_sphere_table())
     rt.set_camera(R.three_camera(7, 5))
