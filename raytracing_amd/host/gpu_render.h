@@ -1,0 +1,82 @@
+// The seam between the reference-shaped host code and the GPU library: flatten a HittableList of
+// Spheres into plain arrays, copy the Camera's fields, make one render call (rt_amd.h), get back the
+// integers main.cpp:138-140 would have produced.  Errors are reported by exception here (host C++);
+// the C ABI underneath reports them by status code.
+#pragma once
+#include <cstdint>
+#include <stdexcept>
+#include <string>
+#include <vector>
+#include "camera.h"
+#include "material.h"
+#include "rt_amd.h"
+
+namespace rtamd {
+
+struct FlatScene {
+    std::vector<float> cx, cy, cz, radius, albedo, param;
+    std::vector<int32_t> material;
+    int size() const { return (int)cx.size(); }
+};
+
+// Walks HittableList::m_oList.  The reference's Material has no type tag, so the concrete class is
+// recovered with dynamic_cast; anything that is not a Sphere with one of the three materials is an error.
+inline FlatScene Flatten(const Hittable* world)
+{
+    const HittableList* list = dynamic_cast<const HittableList*>(world);
+    if (!list) throw std::invalid_argument("Flatten: world is not a HittableList");
+    FlatScene f;
+    for (int i = 0; i < list->m_iListSize; ++i) {
+        const Sphere* s = dynamic_cast<const Sphere*>(list->m_oList[i]);
+        if (!s) throw std::invalid_argument("Flatten: element " + std::to_string(i) + " is not a Sphere");
+        f.cx.push_back(s->m_oCenter[0]); f.cy.push_back(s->m_oCenter[1]); f.cz.push_back(s->m_oCenter[2]);
+        f.radius.push_back(s->m_fRadius);
+        Vec3 albedo(1.0f, 1.0f, 1.0f); float param = 0.0f; int32_t type;
+        if (const Lambertian* l = dynamic_cast<const Lambertian*>(s->m_oMaterial)) { type = RT_LAMBERTIAN; albedo = l->m_oAlbedo; }
+        else if (const Metal* m = dynamic_cast<const Metal*>(s->m_oMaterial)) { type = RT_METAL; albedo = m->m_oAlbedo; param = m->m_fFuzz; }
+        else if (const Dielectric* d = dynamic_cast<const Dielectric*>(s->m_oMaterial)) { type = RT_DIELECTRIC; param = d->m_fRefIdx; }
+        else throw std::invalid_argument("Flatten: sphere " + std::to_string(i) + " has an unknown material");
+        f.material.push_back(type);
+        for (int k = 0; k < 3; ++k) f.albedo.push_back(albedo[k]);
+        f.param.push_back(param);
+    }
+    return f;
+}
+
+inline rt_camera_pod ToPod(const Camera& c)
+{
+    rt_camera_pod p;
+    for (int k = 0; k < 3; ++k) {
+        p.origin[k] = c.m_oOrigin[k]; p.lower_left_corner[k] = c.m_oLowerLeftCorner[k];
+        p.horizontal[k] = c.m_oHorizontal[k]; p.vertical[k] = c.m_oVertical[k];
+        p.u[k] = c.m_oU[k]; p.v[k] = c.m_oV[k]; p.w[k] = c.m_oW[k];
+    }
+    p.lens_radius = c.m_fLensRadius;
+    return p;
+}
+
+struct RenderResult { std::vector<int32_t> irgb; uint64_t rays = 0; float kernel_ms = 0.0f; };
+
+// Replaces the nested loop of main.cpp:118-141 for the whole image on GPU `device`.
+inline RenderResult RenderOnGpu(const Hittable* world, const Camera& cam, int nx, int ny, int ns, uint64_t seed = 0, int device = 0)
+{
+    rt_context* ctx = nullptr;
+    if (rt_create(device, &ctx) != RT_OK) throw std::runtime_error(std::string("rt_create: ") + rt_last_error(nullptr));
+    auto check = [&](int rc, const char* what) {
+        if (rc != RT_OK) { std::string msg = std::string(what) + ": " + rt_last_error(ctx); rt_destroy(ctx); throw std::runtime_error(msg); }
+    };
+    const FlatScene f = Flatten(world);
+    check(rt_upload_scene(ctx, f.size(), f.cx.data(), f.cy.data(), f.cz.data(), f.radius.data(), f.material.data(), f.albedo.data(), f.param.data()), "rt_upload_scene");
+    const rt_camera_pod pod = ToPod(cam);
+    check(rt_set_camera(ctx, &pod), "rt_set_camera");
+    rt_params p{};
+    p.width = nx; p.height = ny; p.spp = ns; p.max_depth = 50; p.tmin = 0.001f; p.seed = seed;
+    p.band_rows = ny; p.band_first = 0; p.band_step = 1; p.mode = RT_MODE_MEGAKERNEL;
+    RenderResult out;
+    out.irgb.resize((size_t)nx * ny * 3);
+    check(rt_render(ctx, &p, nullptr, out.irgb.data(), &out.rays, &out.kernel_ms), "rt_render");
+    rt_destroy(ctx);
+    return out;
+}
+
+}  // namespace rtamd
