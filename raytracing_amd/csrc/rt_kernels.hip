@@ -6,6 +6,7 @@
 #include <cstring>
 #include <new>
 #include <string>
+#include <type_traits>
 #include <vector>
 #include "rt_amd.h"
 #include "rt_device.hpp"
@@ -182,6 +183,8 @@ __global__ void __launch_bounds__(kBlock) k_render_mega(const RenderArgs a)
 //            unfused arithmetic (sphere.cpp:15-52) in ascending index order with the shrinking
 //            upper bound of hittablelist.cpp:13-31, so the chosen sphere and t are bit-identical.
 struct TraceArgs {
+    const float4* prec;      // plane-filter records (cx, cz, -(r^2 + slack_i), 0), same padding as frec
+    float plane_s0;          // constant part of the plane filter's per-ray slack
     const float4* frec;      // filter records (cx, cy, cz, |c|^2 - r^2 - slack), padded to a multiple of 32
     const float4* geom; const float4* mat; const Aux* aux; int n, n_pad;
     CameraD cam;
@@ -207,10 +210,11 @@ __device__ unsigned long long g_section_ticks[8];
 #define SECTION_MARK(idx) do { } while (0)
 #endif
 static constexpr int kChunkItems = 512;
-static constexpr int kCandSlots = 24;                           // candidate-list entries per lane (overflow flushes early)
+static constexpr int kCandSlots = 32;                           // candidate-list entries per lane (overflow flushes early)
 static constexpr float kRaySlack = 160.0f * 5.9604645e-08f;   // per-ray slack, relative to |o|^2
+static constexpr float kPlaneRaySlack = 128.0f * 5.9604645e-08f;
 
-template <bool kLds>
+template <bool kLds, bool kPlane>
 __global__ void __launch_bounds__(kBlock) k_trace(const TraceArgs a)
 {
     extern __shared__ float4 smem[];
@@ -303,12 +307,26 @@ __global__ void __launch_bounds__(kBlock) k_trace(const TraceArgs a)
             const float p2x = 2.0f * ray.o.x, p2y = 2.0f * ray.o.y, p2z = 2.0f * ray.o.z;
             const float oo = fmaf(ray.o.x, ray.o.x, fmaf(ray.o.y, ray.o.y, ray.o.z * ray.o.z));
             const float noo = kRaySlack * oo - oo;
+            // Plane filter (kPlane): the vertical plane through the ray has a horizontal normal u perp d, so
+            // the signed distance of a centre to it is pu = cx*ux + cz*uz - o.u (2 FMA).  The reference
+            // accepts a sphere only if its discriminant b^2 - a c is positive, and in its float arithmetic
+            // that can happen for a line passing up to sqrt(r^2 + 32 ulp (|o-c|^2 + r^2)) from the centre,
+            // so the test is pu^2 - R_i <= S_ray with that allowance (and this form's own rounding) split
+            // into a per-sphere part R_i (host) and a per-ray part S_ray: 3 FMA + 1 SUB per pair.
+            float ux = 1.0f, uz = 0.0f, nou = 0.0f, s_ray = 0.0f;
+            if (kPlane) {
+                const float h2 = fmaf(hx, hx, hz * hz);
+                if (h2 > 1e-12f) { const float ih = __frsqrt_rn(h2); ux = hz * ih; uz = -hx * ih; }
+                nou = -fmaf(ray.o.x, ux, ray.o.z * uz);
+                s_ray = fmaf(kPlaneRaySlack, oo, a.plane_s0);
+            }
             float closest = FLT_MAX; int hit = -1;
             // Filter records are read through the constant address space: the index is wave-uniform,
             // so each record arrives by scalar load in SGPRs and feeds the FMAs as a scalar operand.
             typedef float f4v __attribute__((ext_vector_type(4)));
             typedef const __attribute__((address_space(4))) f4v* ConstRec;
             const ConstRec frec_k = (ConstRec)(a.frec);
+            const ConstRec prec_k = (ConstRec)(a.prec);
             int cnt = 0;
 
             // Exact test of the listed candidates, ascending index, shrinking upper bound: the
@@ -332,19 +350,30 @@ __global__ void __launch_bounds__(kBlock) k_trace(const TraceArgs a)
             };
 
             SECTION_MARK(1);
-            for (int base = 0; base < a.n_pad; base += 32) {
+            // One chunk = kCount consecutive records -> kCount sign bits (bit 31 = first record) -> the
+            // survivors appended to the lane's candidate list.  Full chunks of 32, then chunks of 8.
+            auto chunk = [&](int base, auto count_tag) {
+                constexpr int kCount = decltype(count_tag)::value;
                 uint32_t mask = 0u;
 #pragma unroll
-                for (int jj = 0; jj < 32; ++jj) {
-                    const f4v f = frec_k[base + jj];
-                    const float b = fmaf(f.x, hx, fmaf(f.y, hy, fmaf(f.z, hz, nod)));
-                    const float w = fmaf(f.x, p2x, fmaf(f.y, p2y, fmaf(f.z, p2z, noo)));
-                    const float e = fmaf(b, b, w);
-                    const float sgn = e - f.w;
+                for (int jj = 0; jj < kCount; ++jj) {
+                    float sgn;
+                    if (kPlane) {
+                        const f4v f = prec_k[base + jj];
+                        const float pu = fmaf(f.x, ux, fmaf(f.y, uz, nou));
+                        sgn = s_ray - fmaf(pu, pu, f.z);
+                    } else {
+                        const f4v f = frec_k[base + jj];
+                        const float b = fmaf(f.x, hx, fmaf(f.y, hy, fmaf(f.z, hz, nod)));
+                        const float w = fmaf(f.x, p2x, fmaf(f.y, p2y, fmaf(f.z, p2z, noo)));
+                        const float e = fmaf(b, b, w);
+                        sgn = e - f.w;
+                    }
                     mask = __builtin_amdgcn_alignbit(mask, __float_as_uint(sgn), 31);   // append sign bit
                 }
                 SECTION_MARK(2);
-                uint32_t cand = ~mask;      // bit 31 = sphere `base`, bit 0 = sphere base + 31
+                uint32_t cand = ~mask;
+                if (kCount < 32) cand <<= (32 - kCount);
                 while (cand) {
                     const int jj = __clz((int)cand);
                     cand &= ~(0x80000000u >> jj);
@@ -355,7 +384,10 @@ __global__ void __launch_bounds__(kBlock) k_trace(const TraceArgs a)
                     }
                 }
                 SECTION_MARK(3);
-            }
+            };
+            int base = 0;
+            for (; base + 32 <= a.n_pad; base += 32) chunk(base, std::integral_constant<int, 32>());
+            for (; base < a.n_pad; base += 8) chunk(base, std::integral_constant<int, 8>());
             flush();
             SECTION_MARK(4);
             ++rays;
@@ -480,12 +512,13 @@ struct rt_context {
     int device = -1;
     std::string error;
     float4* d_geom = nullptr; float4* d_mat = nullptr; Aux* d_aux = nullptr; int n = 0;
-    float4* d_frec = nullptr; int n_pad = 0;
+    float4* d_frec = nullptr; float4* d_prec = nullptr; float plane_s0 = 0.0f; int n_pad = 0;
+    bool plane_filter = true;
     float* d_samples = nullptr; size_t samples_bytes = 0;      // sample buffer of the persistent megakernel
     float* d_accum = nullptr; size_t accum_bytes = 0;          // running per-pixel sums across sample batches
     unsigned int* d_work = nullptr;
     uint16_t* d_stacks = nullptr; size_t stacks_lanes = 0;
-    int num_cu = 0; int trace_blocks_per_cu[2] = { 0, 0 };
+    int num_cu = 0; int trace_blocks_per_cu[4] = { 0, 0, 0, 0 };
     bool have_camera = false; CameraD cam{};
     unsigned long long* d_rays = nullptr;
     hipEvent_t ev0 = nullptr, ev1 = nullptr; hipStream_t last_stream = nullptr; bool pending = false;
@@ -563,6 +596,8 @@ int rt_create(int device_ordinal, rt_context** out)
     rt_context* ctx = new (std::nothrow) rt_context;
     if (!ctx) return fail(nullptr, RT_ERR_HIP, "rt_create: out of host memory");
     ctx->device = device_ordinal;
+    // RT_AMD_FILTER=disc selects the full-discriminant filter instead of the plane filter (A/B runs).
+    { const char* f = getenv("RT_AMD_FILTER"); ctx->plane_filter = !(f && strcmp(f, "disc") == 0); }
     hipError_t e = hipSetDevice(device_ordinal);
     if (e == hipSuccess) e = hipMalloc(&ctx->d_rays, sizeof(unsigned long long));
     if (e == hipSuccess) e = hipMalloc(&ctx->d_work, sizeof(unsigned int));
@@ -580,7 +615,7 @@ void rt_destroy(rt_context* ctx)
     (void)hipSetDevice(ctx->device);
     if (ctx->pending) (void)hipStreamSynchronize(ctx->last_stream);
     (void)hipFree(ctx->d_geom); (void)hipFree(ctx->d_mat); (void)hipFree(ctx->d_aux); (void)hipFree(ctx->d_rays);
-    (void)hipFree(ctx->d_frec); (void)hipFree(ctx->d_samples); (void)hipFree(ctx->d_accum); (void)hipFree(ctx->d_work); (void)hipFree(ctx->d_stacks);
+    (void)hipFree(ctx->d_frec); (void)hipFree(ctx->d_prec); (void)hipFree(ctx->d_samples); (void)hipFree(ctx->d_accum); (void)hipFree(ctx->d_work); (void)hipFree(ctx->d_stacks);
     if (ctx->ev0) (void)hipEventDestroy(ctx->ev0);
     if (ctx->ev1) (void)hipEventDestroy(ctx->ev1);
     delete ctx;
@@ -595,7 +630,7 @@ int rt_upload_scene(rt_context* ctx, int n, const float* cx, const float* cy, co
     if (n <= 0 || !cx || !cy || !cz || !radius || !material || !albedo_rgb || !param) return fail(ctx, RT_ERR_INVALID, "rt_upload_scene: null array or n <= 0");
     if (n > 65535) return fail(ctx, RT_ERR_TOO_LARGE, "rt_upload_scene: %d spheres exceeds the 65535 limit of the 16-bit hit stack", n);
     std::vector<float4> geom(n), mat(n); std::vector<Aux> aux(n);
-    const int n_pad = (n + 31) / 32 * 32;
+    const int n_pad = (n + 7) / 8 * 8;
     // Filter records (cx, cy, cz, k), k = |c|^2 - r^2 - slack_i.  With u = 2^-24, M = |o| + |c| and the
     // ray direction normalised, the filter's own rounding error is below 32 u M^2 and the reference's
     // discriminant (divided by |d|^2) is off by less than 32 u (|o - c|^2 + r^2); since
@@ -609,6 +644,21 @@ int rt_upload_scene(rt_context* ctx, int n, const float* cx, const float* cy, co
         if ((double)kf > k) kf = nextafterf(kf, -INFINITY);
         frec[i] = make_float4(cx[i], cy[i], cz[i], kf);
     }
+    // Plane-filter records (cx, cz, -(r^2 + slack_i), 0).  u = 2^-24.  Allowance for the reference's own
+    // discriminant rounding: 32 u (|o-c|^2 + r^2) <= 64 u (|o|^2 + |c|^2) + 32 u r^2; this form's rounding
+    // of pu (< 8 u (|c| + |o|)) moves pu^2 near the threshold by < 16 u |r| (|c| + |o|)
+    // <= 8 u (2 r^2 + |c|^2 + |o|^2).  slack_i = u (128 |c|^2 + 64 r^2), S_ray = u (128 |o|^2 + 32 max r^2).
+    std::vector<float4> prec(n_pad, make_float4(0.0f, 0.0f, FLT_MAX, 0.0f));
+    double r2max = 0.0;
+    for (int i = 0; i < n; ++i) { const double rr = (double)radius[i] * radius[i]; if (rr > r2max) r2max = rr; }
+    for (int i = 0; i < n; ++i) {
+        const double rr = (double)radius[i] * radius[i];
+        const double cc = (double)cx[i] * cx[i] + (double)cy[i] * cy[i] + (double)cz[i] * cz[i];
+        const double R = rr + 5.9604644775390625e-08 * (128.0 * cc + 64.0 * rr) + 1e-30;
+        float rf = (float)R; if ((double)rf < R) rf = nextafterf(rf, INFINITY);
+        prec[i] = make_float4(cx[i], cz[i], -rf, 0.0f);
+    }
+    const float plane_s0 = (float)(32.0 * 5.9604644775390625e-08 * r2max) * 1.0001f + 1e-30f;
     for (int i = 0; i < n; ++i) {
         if (material[i] < RT_LAMBERTIAN || material[i] > RT_DIELECTRIC) return fail(ctx, RT_ERR_INVALID, "rt_upload_scene: sphere %d has unknown material %d", i, material[i]);
         geom[i] = make_float4(cx[i], cy[i], cz[i], radius[i] * radius[i]);
@@ -618,8 +668,11 @@ int rt_upload_scene(rt_context* ctx, int n, const float* cx, const float* cy, co
     }
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     if (ctx->pending) { HIP_TRY(ctx, hipStreamSynchronize(ctx->last_stream)); ctx->pending = false; }
-    (void)hipFree(ctx->d_geom); (void)hipFree(ctx->d_mat); (void)hipFree(ctx->d_aux); (void)hipFree(ctx->d_frec);
-    ctx->d_geom = nullptr; ctx->d_mat = nullptr; ctx->d_aux = nullptr; ctx->d_frec = nullptr; ctx->n = 0;
+    (void)hipFree(ctx->d_geom); (void)hipFree(ctx->d_mat); (void)hipFree(ctx->d_aux); (void)hipFree(ctx->d_frec); (void)hipFree(ctx->d_prec);
+    ctx->d_geom = nullptr; ctx->d_mat = nullptr; ctx->d_aux = nullptr; ctx->d_frec = nullptr; ctx->d_prec = nullptr; ctx->n = 0;
+    HIP_TRY(ctx, hipMalloc(&ctx->d_prec, sizeof(float4) * n_pad));
+    HIP_TRY(ctx, hipMemcpy(ctx->d_prec, prec.data(), sizeof(float4) * n_pad, hipMemcpyHostToDevice));
+    ctx->plane_s0 = plane_s0;
     HIP_TRY(ctx, hipMalloc(&ctx->d_frec, sizeof(float4) * n_pad));
     HIP_TRY(ctx, hipMemcpy(ctx->d_frec, frec.data(), sizeof(float4) * n_pad, hipMemcpyHostToDevice));
     ctx->n_pad = n_pad;
@@ -700,11 +753,12 @@ int rt_render_device(rt_context* ctx, const rt_params* p, float* d_rgb_mean, int
         }
         const bool lds = ctx->n <= kMaxLdsSpheres;
         const size_t shmem = (lds ? (size_t)ctx->n * kLdsBytesPerSphere : 0) + (size_t)(kBlock / 64) * kCandSlots * 64 * sizeof(uint16_t);
-        int& bpc = ctx->trace_blocks_per_cu[lds ? 1 : 0];
+        const bool plane = ctx->plane_filter;
+        int& bpc = ctx->trace_blocks_per_cu[(lds ? 1 : 0) + (plane ? 2 : 0)];
         if (bpc == 0) {
             int nb = 0;
-            hipError_t e = lds ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_trace<true>, kBlock, shmem)
-                               : hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_trace<false>, kBlock, shmem);
+            auto kern = lds ? (plane ? k_trace<true, true> : k_trace<true, false>) : (plane ? k_trace<false, true> : k_trace<false, false>);
+            hipError_t e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, kern, kBlock, shmem);
             if (e != hipSuccess || nb <= 0) nb = 1;
             bpc = nb;
         }
@@ -717,7 +771,7 @@ int rt_render_device(rt_context* ctx, const rt_params* p, float* d_rgb_mean, int
         for (int bi = 0, s0 = 0; bi < batches; ++bi, s0 += s_per) {
             const int sc = (p->spp - s0 < s_per) ? p->spp - s0 : s_per;
             TraceArgs a;
-            a.frec = ctx->d_frec; a.geom = ctx->d_geom; a.mat = ctx->d_mat; a.aux = ctx->d_aux; a.n = ctx->n; a.n_pad = ctx->n_pad; a.cam = ctx->cam;
+            a.prec = ctx->d_prec; a.plane_s0 = ctx->plane_s0; a.frec = ctx->d_frec; a.geom = ctx->d_geom; a.mat = ctx->d_mat; a.aux = ctx->d_aux; a.n = ctx->n; a.n_pad = ctx->n_pad; a.cam = ctx->cam;
             a.width = p->width; a.height = p->height; a.max_depth = p->max_depth; a.tmin = p->tmin;
             a.k0 = (uint32_t)p->seed; a.k1 = (uint32_t)(p->seed >> 32);
             a.band_rows = p->band_rows; a.band_first = p->band_first; a.band_step = p->band_step; a.owned_rows = owned;
@@ -728,8 +782,10 @@ int rt_render_device(rt_context* ctx, const rt_params* p, float* d_rgb_mean, int
             uint64_t want_blocks = ((uint64_t)a.total_items + kChunkItems * 4 - 1) / (kChunkItems * 4);
             const uint64_t cap_blocks = (uint64_t)ctx->num_cu * bpc;
             const dim3 grid((unsigned)(want_blocks < cap_blocks ? want_blocks : cap_blocks)), block(kBlock);
-            if (lds) hipLaunchKernelGGL(k_trace<true>, grid, block, shmem, st, a);
-            else hipLaunchKernelGGL(k_trace<false>, grid, block, shmem, st, a);
+            if (lds && plane) hipLaunchKernelGGL((k_trace<true, true>), grid, block, shmem, st, a);
+            else if (lds) hipLaunchKernelGGL((k_trace<true, false>), grid, block, shmem, st, a);
+            else if (plane) hipLaunchKernelGGL((k_trace<false, true>), grid, block, shmem, st, a);
+            else hipLaunchKernelGGL((k_trace<false, false>), grid, block, shmem, st, a);
             HIP_TRY(ctx, hipGetLastError());
             ResolveArgs r;
             r.samples = ctx->d_samples; r.accum = ctx->d_accum; r.Q = (uint32_t)Q; r.tiles_x = tiles_x; r.s_count = sc;
