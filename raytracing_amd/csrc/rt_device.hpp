@@ -49,17 +49,12 @@ __device__ __forceinline__ float u01(uint32_t w) { return (float)(w >> 8) * (1.0
 // Keyed provider: draw d of the current slot is word d%4 of group d/4 (all four words of a Philox
 // block are consumed before the next block is computed).
 struct KeyedUniforms {
-    uint32_t px, smp, bounce, k0, k1, draw; U4 cur;
-    __device__ __forceinline__ void slot(uint32_t p, uint32_t s, uint32_t b) { px = p; smp = s; bounce = b; draw = 0; }
-    // Computes group 0 of the current slot ahead of its first use (lets divergent consumers share it).
+    uint32_t px, smp, bounce, k0, k1; U4 cur;
+    __device__ __forceinline__ void slot(uint32_t p, uint32_t s, uint32_t b) { px = p; smp = s; bounce = b; }
+    // Computes group 0 of the current slot (shared by whichever material consumes it).
     __device__ __forceinline__ void prefetch() { cur = philox4x32_10(px, smp, bounce, 0u, k0, k1); }
-    __device__ __forceinline__ float f()
-    {
-        const uint32_t w = draw & 3u;
-        if (w == 0 && draw != 0) cur = philox4x32_10(px, smp, bounce, draw >> 2, k0, k1);
-        ++draw;
-        return u01(w == 0 ? cur.x : (w == 1 ? cur.y : (w == 2 ? cur.z : cur.w)));
-    }
+    // First draw of the slot (Dielectric::Scatter's only draw).
+    __device__ __forceinline__ float f() { return u01(cur.x); }
     __device__ __forceinline__ double d() { return (double)f(); }
 };
 // Replay provider for the unit-level entry points: recorded rand() integers.
@@ -112,6 +107,29 @@ __device__ __forceinline__ float schlick(float cosine, float ref_idx)
     // differs from libm's pow by at most a few double ulps, far below float resolution.
     const double x = (double)(1.0f - cosine), x2 = x * x;
     return (float)((double)r0 + (double)(1.0f - r0) * (x2 * x2 * x));
+}
+// Keyed stream: the draws of RandomInUnitSphere() are words 0,1,2 | 3,4,5 | ... of the slot, i.e. four
+// rejection iterations per three Philox blocks.  Written out with static word selection (a runtime
+// word index would put the block into scratch memory).  u.cur must hold group 0 (prefetch()).
+__device__ __forceinline__ bool unit_ball_try(uint32_t wz, uint32_t wy, uint32_t wx, V3& p)
+{
+    p = 2.0f * mk(u01(wx), u01(wy), u01(wz)) - mk(1.0f, 1.0f, 1.0f);   // first draw is z: right-to-left argument order
+    return !(sqlen(p) >= 1.0f);
+}
+__device__ __forceinline__ V3 random_in_unit_sphere(KeyedUniforms& u)
+{
+    V3 p;
+    U4 b0 = u.cur;
+    for (uint32_t g = 0;; g += 3) {
+        if (g != 0) b0 = philox4x32_10(u.px, u.smp, u.bounce, g, u.k0, u.k1);
+        if (unit_ball_try(b0.x, b0.y, b0.z, p)) break;
+        const U4 b1 = philox4x32_10(u.px, u.smp, u.bounce, g + 1u, u.k0, u.k1);
+        if (unit_ball_try(b0.w, b1.x, b1.y, p)) break;
+        const U4 b2 = philox4x32_10(u.px, u.smp, u.bounce, g + 2u, u.k0, u.k1);
+        if (unit_ball_try(b1.z, b1.w, b2.x, p)) break;
+        if (unit_ball_try(b2.y, b2.z, b2.w, p)) break;
+    }
+    return p;
 }
 template <class U>
 __device__ __forceinline__ V3 random_in_unit_sphere(U& u)

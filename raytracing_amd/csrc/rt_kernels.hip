@@ -210,7 +210,7 @@ __device__ unsigned long long g_section_ticks[8];
 #define SECTION_MARK(idx) do { } while (0)
 #endif
 static constexpr int kChunkItems = 512;
-static constexpr int kCandSlots = 32;                           // candidate-list entries per lane (overflow flushes early)
+static constexpr int kSuperChunkWords = 16;                     // 32-sphere mask words kept per lane between exact passes (512 spheres)
 static constexpr float kRaySlack = 160.0f * 5.9604645e-08f;   // per-ray slack, relative to |o|^2
 static constexpr float kPlaneRaySlack = 128.0f * 5.9604645e-08f;
 
@@ -227,8 +227,8 @@ __global__ void __launch_bounds__(kBlock) k_trace(const TraceArgs a)
     }
     __syncthreads();
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    // Per-lane candidate list: slot c of lane l at cand_list[c * 64] (2-byte entries, lanes contiguous).
-    uint16_t* cand_list = reinterpret_cast<uint16_t*>(reinterpret_cast<char*>(smem) + (kLds ? (size_t)a.n * kLdsBytesPerSphere : 0)) + (size_t)wave * kCandSlots * 64 + lane;
+    // Per-lane filter masks of one super-chunk: word w of lane l at mask_words[w * 64] (lanes contiguous).
+    uint32_t* mask_words = reinterpret_cast<uint32_t*>(reinterpret_cast<char*>(smem) + (kLds ? (size_t)a.n * kLdsBytesPerSphere : 0)) + (size_t)wave * kSuperChunkWords * 64 + lane;
     // The recursion's attenuation chain is replayed innermost-first when a path reaches the sky, so
     // each lane keeps the indices of the spheres it bounced off.  One 2-byte store per bounce and a
     // short read-back per finished path: kept in HBM so that LDS does not limit occupancy.
@@ -236,7 +236,7 @@ __global__ void __launch_bounds__(kBlock) k_trace(const TraceArgs a)
     const size_t sstride = a.stack_stride;
     (void)wave;
 
-    KeyedUniforms U; U.k0 = a.k0; U.k1 = a.k1; U.slot(0, 0, 0);
+    KeyedUniforms U; U.k0 = a.k0; U.k1 = a.k1; U.slot(0, 0, 0); U.cur = U4{ 0, 0, 0, 0 };
     RayD ray; ray.o = mk(0, 0, 0); ray.d = mk(0, 0, 1);
     int depth = 0; uint32_t item = 0, pix = 0, smp = 0;
     bool active = false;
@@ -327,32 +327,10 @@ __global__ void __launch_bounds__(kBlock) k_trace(const TraceArgs a)
             typedef const __attribute__((address_space(4))) f4v* ConstRec;
             const ConstRec frec_k = (ConstRec)(a.frec);
             const ConstRec prec_k = (ConstRec)(a.prec);
-            int cnt = 0;
 
-            // Exact test of the listed candidates, ascending index, shrinking upper bound: the
-            // arithmetic of sphere.cpp:15-52 / hittablelist.cpp:21-29, unfused.
-            auto flush = [&]() {
-                for (int c = 0; c < cnt; ++c) {
-                    const int k = cand_list[c * 64];
-                    const float4 g = kLds ? s_geom[k] : a.geom[k];
-                    const V3 oc = ray.o - mk(g.x, g.y, g.z);
-                    const float b = dot(oc, ray.d);
-                    const float cc = dot(oc, oc) - g.w;
-                    const float desc = b * b - qa * cc;
-                    if (desc > 0.0f) {
-                        const float sq = sqrtf(desc);
-                        float temp = (-b - sq) / qa;
-                        if (!(temp < closest && temp > a.tmin)) temp = (-b + sq) / qa;
-                        if (temp < closest && temp > a.tmin) { closest = temp; hit = k; }
-                    }
-                }
-                cnt = 0;
-            };
-
-            SECTION_MARK(1);
-            // One chunk = kCount consecutive records -> kCount sign bits (bit 31 = first record) -> the
-            // survivors appended to the lane's candidate list.  Full chunks of 32, then chunks of 8.
-            auto chunk = [&](int base, auto count_tag) {
+            // Filter one 32-sphere chunk (or a shorter tail, a multiple of 8): kCount sign bits, left-aligned
+            // (bit 31 = first record of the chunk), 1 = rejected.
+            auto filter_bits = [&](int base, auto count_tag) -> uint32_t {
                 constexpr int kCount = decltype(count_tag)::value;
                 uint32_t mask = 0u;
 #pragma unroll
@@ -371,24 +349,62 @@ __global__ void __launch_bounds__(kBlock) k_trace(const TraceArgs a)
                     }
                     mask = __builtin_amdgcn_alignbit(mask, __float_as_uint(sgn), 31);   // append sign bit
                 }
+                return mask;
+            };
+
+            SECTION_MARK(1);
+            // Super-chunks of up to 16 mask words (512 spheres).  The filter only stores each word and notes
+            // whether it has a survivor; afterwards one loop per lane walks its surviving bits in ascending
+            // sphere order and runs the exact test of sphere.cpp:15-52 with the shrinking upper bound of
+            // hittablelist.cpp:21-29 (unfused arithmetic).
+            for (int sbase = 0; sbase < a.n_pad; sbase += 32 * kSuperChunkWords) {
+                uint32_t nz = 0u;          // bit (31 - w) set: word w of this super-chunk has a survivor
+                int words = 0;
+                int base = sbase;
+                const int send = (a.n_pad - sbase < 32 * kSuperChunkWords) ? a.n_pad : sbase + 32 * kSuperChunkWords;
+                for (; base + 32 <= send; base += 32, ++words) {
+                    const uint32_t cand = ~filter_bits(base, std::integral_constant<int, 32>());
+                    mask_words[words * 64] = cand;
+                    nz = __builtin_amdgcn_alignbit(nz, cand | (0u - cand), 31);
+                }
+                if (base < send) {         // tail: 8, 16 or 24 records
+                    uint32_t m = 0u; int got = 0;
+                    for (; base < send; base += 8, got += 8) m = (m << 8) | filter_bits(base, std::integral_constant<int, 8>());
+                    const uint32_t cand = (~m) << (32 - got);
+                    mask_words[words * 64] = cand;
+                    nz = __builtin_amdgcn_alignbit(nz, cand | (0u - cand), 31);
+                    ++words;
+                }
+                nz <<= (32 - words);
                 SECTION_MARK(2);
-                uint32_t cand = ~mask;
-                if (kCount < 32) cand <<= (32 - kCount);
-                while (cand) {
+                uint32_t cand = 0u; int cbase = 0;
+                for (;;) {
+                    if (cand == 0u) {
+                        if (nz == 0u) break;
+                        const int w = __clz((int)nz);
+                        nz &= ~(0x80000000u >> w);
+                        cand = mask_words[w * 64];
+                        cbase = sbase + (w << 5);
+                    }
                     const int jj = __clz((int)cand);
                     cand &= ~(0x80000000u >> jj);
-                    const int k = base + jj;
+                    const int k = cbase + jj;
                     if (k < a.n) {
-                        if (cnt == kCandSlots) flush();
-                        cand_list[cnt * 64] = (uint16_t)k; ++cnt;
+                        const float4 g = kLds ? s_geom[k] : a.geom[k];
+                        const V3 oc = ray.o - mk(g.x, g.y, g.z);
+                        const float b = dot(oc, ray.d);
+                        const float cc = dot(oc, oc) - g.w;
+                        const float desc = b * b - qa * cc;
+                        if (desc > 0.0f) {
+                            const float sq = sqrtf(desc);
+                            float temp = (-b - sq) / qa;
+                            if (!(temp < closest && temp > a.tmin)) temp = (-b + sq) / qa;
+                            if (temp < closest && temp > a.tmin) { closest = temp; hit = k; }
+                        }
                     }
                 }
                 SECTION_MARK(3);
-            };
-            int base = 0;
-            for (; base + 32 <= a.n_pad; base += 32) chunk(base, std::integral_constant<int, 32>());
-            for (; base < a.n_pad; base += 8) chunk(base, std::integral_constant<int, 8>());
-            flush();
+            }
             SECTION_MARK(4);
             ++rays;
             // ------------------------------------------------------------ shade (main.cpp:13-39)
@@ -647,10 +663,8 @@ int rt_upload_scene(rt_context* ctx, int n, const float* cx, const float* cy, co
     // Plane-filter records (cx, cz, -(r^2 + slack_i), 0).  u = 2^-24.  Allowance for the reference's own
     // discriminant rounding: 32 u (|o-c|^2 + r^2) <= 64 u (|o|^2 + |c|^2) + 32 u r^2; this form's rounding
     // of pu (< 8 u (|c| + |o|)) moves pu^2 near the threshold by < 16 u |r| (|c| + |o|)
-    // <= 8 u (2 r^2 + |c|^2 + |o|^2).  slack_i = u (128 |c|^2 + 64 r^2), S_ray = u (128 |o|^2 + 32 max r^2).
+    // <= 8 u (2 r^2 + |c|^2 + |o|^2).  slack_i = u (128 |c|^2 + 64 r^2), S_ray = 128 u |o|^2 (kernel).
     std::vector<float4> prec(n_pad, make_float4(0.0f, 0.0f, FLT_MAX, 0.0f));
-    double r2max = 0.0;
-    for (int i = 0; i < n; ++i) { const double rr = (double)radius[i] * radius[i]; if (rr > r2max) r2max = rr; }
     for (int i = 0; i < n; ++i) {
         const double rr = (double)radius[i] * radius[i];
         const double cc = (double)cx[i] * cx[i] + (double)cy[i] * cy[i] + (double)cz[i] * cz[i];
@@ -658,7 +672,7 @@ int rt_upload_scene(rt_context* ctx, int n, const float* cx, const float* cy, co
         float rf = (float)R; if ((double)rf < R) rf = nextafterf(rf, INFINITY);
         prec[i] = make_float4(cx[i], cz[i], -rf, 0.0f);
     }
-    const float plane_s0 = (float)(32.0 * 5.9604644775390625e-08 * r2max) * 1.0001f + 1e-30f;
+    const float plane_s0 = 1e-30f;
     for (int i = 0; i < n; ++i) {
         if (material[i] < RT_LAMBERTIAN || material[i] > RT_DIELECTRIC) return fail(ctx, RT_ERR_INVALID, "rt_upload_scene: sphere %d has unknown material %d", i, material[i]);
         geom[i] = make_float4(cx[i], cy[i], cz[i], radius[i] * radius[i]);
@@ -752,7 +766,7 @@ int rt_render_device(rt_context* ctx, const rt_params* p, float* d_rgb_mean, int
             HIP_TRY(ctx, hipMalloc(&ctx->d_accum, Q * 12)); ctx->accum_bytes = Q * 12;
         }
         const bool lds = ctx->n <= kMaxLdsSpheres;
-        const size_t shmem = (lds ? (size_t)ctx->n * kLdsBytesPerSphere : 0) + (size_t)(kBlock / 64) * kCandSlots * 64 * sizeof(uint16_t);
+        const size_t shmem = (lds ? (size_t)ctx->n * kLdsBytesPerSphere : 0) + (size_t)(kBlock / 64) * kSuperChunkWords * 64 * sizeof(uint32_t);
         const bool plane = ctx->plane_filter;
         int& bpc = ctx->trace_blocks_per_cu[(lds ? 1 : 0) + (plane ? 2 : 0)];
         if (bpc == 0) {
