@@ -211,13 +211,14 @@ __device__ unsigned long long g_section_ticks[8];
 #define SECTION_MARK(idx) do { } while (0)
 #endif
 static constexpr int kChunkItems = 512;
+static constexpr int kTraceBlock = 512;         // 8 waves share one LDS copy of the scene records
 __device__ __forceinline__ float staged_load(const float* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 static constexpr int kSuperChunkWords = 16;                     // 32-sphere mask words kept per lane between exact passes (512 spheres)
 static constexpr float kRaySlack = 160.0f * 5.9604645e-08f;   // per-ray slack, relative to |o|^2
 static constexpr float kPlaneRaySlack = 128.0f * 5.9604645e-08f;
 
 template <bool kLds, bool kPlane>
-__global__ void __launch_bounds__(kBlock) k_trace(const TraceArgs a)
+__global__ void __launch_bounds__(kTraceBlock) k_trace(const TraceArgs a)
 {
     extern __shared__ float4 smem[];
     // LDS: [geom n][mat n][aux n (8 B)] when kLds.
@@ -225,7 +226,7 @@ __global__ void __launch_bounds__(kBlock) k_trace(const TraceArgs a)
     float4* s_mat = smem + (kLds ? a.n : 0);
     Aux* s_aux = reinterpret_cast<Aux*>(smem + (kLds ? 2 * a.n : 0));
     if (kLds) {
-        for (int i = threadIdx.x; i < a.n; i += kBlock) { s_geom[i] = a.geom[i]; s_mat[i] = a.mat[i]; s_aux[i] = a.aux[i]; }
+        for (int i = threadIdx.x; i < a.n; i += kTraceBlock) { s_geom[i] = a.geom[i]; s_mat[i] = a.mat[i]; s_aux[i] = a.aux[i]; }
     }
     __syncthreads();
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
@@ -235,7 +236,7 @@ __global__ void __launch_bounds__(kBlock) k_trace(const TraceArgs a)
     // each lane keeps the indices of the spheres it bounced off.  One 2-byte store per bounce and a
     // short read-back per finished path: kept in HBM so that LDS does not limit occupancy (packing the
     // first levels into registers was measured 1.5 % slower: the loads are hidden by the other waves).
-    uint16_t* stack = a.stacks + (size_t)blockIdx.x * kBlock + threadIdx.x;
+    uint16_t* stack = a.stacks + (size_t)blockIdx.x * kTraceBlock + threadIdx.x;
     const size_t sstride = a.stack_stride;
 
     KeyedUniforms U; U.k0 = a.k0; U.k1 = a.k1; U.slot(0, 0, 0); U.cur = U4{ 0, 0, 0, 0 };
@@ -244,7 +245,7 @@ __global__ void __launch_bounds__(kBlock) k_trace(const TraceArgs a)
     bool active = false;
     uint32_t rays = 0;
     uint32_t pool_next = 0, pool_end = 0, pool_base = 0;      // wave-uniform
-    float* staged = a.staging + ((size_t)blockIdx.x * (kBlock / 64) + wave) * (8 * kChunkItems);
+    float* staged = a.staging + ((size_t)blockIdx.x * (kTraceBlock / 64) + wave) * (8 * kChunkItems);
     bool exhausted = false;                    // wave-uniform
     const float fnx = (float)a.width, fny = (float)a.height;
 #ifdef RT_SECTION_TIMERS
@@ -792,17 +793,17 @@ int rt_render_device(rt_context* ctx, const rt_params* p, float* d_rgb_mean, int
             HIP_TRY(ctx, hipMalloc(&ctx->d_accum, Q * 12)); ctx->accum_bytes = Q * 12;
         }
         const bool lds = ctx->n <= kMaxLdsSpheres;
-        const size_t shmem = (lds ? (size_t)ctx->n * kLdsBytesPerSphere : 0) + (size_t)(kBlock / 64) * kSuperChunkWords * 64 * sizeof(uint32_t);
+        const size_t shmem = (lds ? (size_t)ctx->n * kLdsBytesPerSphere : 0) + (size_t)(kTraceBlock / 64) * kSuperChunkWords * 64 * sizeof(uint32_t);
         const bool plane = ctx->plane_filter;
         int& bpc = ctx->trace_blocks_per_cu[(lds ? 1 : 0) + (plane ? 2 : 0)];
         if (bpc == 0) {
             int nb = 0;
             auto kern = lds ? (plane ? k_trace<true, true> : k_trace<true, false>) : (plane ? k_trace<false, true> : k_trace<false, false>);
-            hipError_t e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, kern, kBlock, shmem);
+            hipError_t e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, kern, kTraceBlock, shmem);
             if (e != hipSuccess || nb <= 0) nb = 1;
             bpc = nb;
         }
-        const size_t lanes = (size_t)ctx->num_cu * bpc * kBlock;
+        const size_t lanes = (size_t)ctx->num_cu * bpc * kTraceBlock;
         if (ctx->stacks_lanes < lanes) {
             HIP_TRY(ctx, hipStreamSynchronize(st));
             (void)hipFree(ctx->d_stacks); ctx->d_stacks = nullptr; ctx->stacks_lanes = 0;
@@ -822,9 +823,9 @@ int rt_render_device(rt_context* ctx, const rt_params* p, float* d_rgb_mean, int
             a.samples = ctx->d_samples; a.ray_counter = ctx->d_rays; a.work_counter = ctx->d_work;
             a.stacks = ctx->d_stacks; a.stack_stride = (uint32_t)ctx->stacks_lanes; a.staging = ctx->d_staging;
             HIP_TRY(ctx, hipMemsetAsync(ctx->d_work, 0, sizeof(unsigned int), st));
-            uint64_t want_blocks = ((uint64_t)a.total_items + kChunkItems * 4 - 1) / (kChunkItems * 4);
+            uint64_t want_blocks = ((uint64_t)a.total_items + kChunkItems * (kTraceBlock / 64) - 1) / (kChunkItems * (kTraceBlock / 64));
             const uint64_t cap_blocks = (uint64_t)ctx->num_cu * bpc;
-            const dim3 grid((unsigned)(want_blocks < cap_blocks ? want_blocks : cap_blocks)), block(kBlock);
+            const dim3 grid((unsigned)(want_blocks < cap_blocks ? want_blocks : cap_blocks)), block(kTraceBlock);
             if (lds && plane) hipLaunchKernelGGL((k_trace<true, true>), grid, block, shmem, st, a);
             else if (lds) hipLaunchKernelGGL((k_trace<true, false>), grid, block, shmem, st, a);
             else if (plane) hipLaunchKernelGGL((k_trace<false, true>), grid, block, shmem, st, a);
