@@ -402,31 +402,62 @@ __global__ void __launch_bounds__(kTraceBlock) k_trace(const TraceArgs a)
                     ++words;
                 }
                 nz <<= (32 - words);
-                SECTION_MARK(2);
-                uint32_t cand = 0u; int cbase = 0;
-                for (;;) {
-                    if (cand == 0u) {
-                        if (nz == 0u) break;
-                        const int w = __clz((int)nz);
-                        nz &= ~(0x80000000u >> w);
-                        cand = mask_words[w * 64];
-                        cbase = sbase + (w << 5);
+                SECTION_MARK(1);
+                // Pass A: exact discriminant of every survivor of the filter (sphere.cpp:17-25); the bits of
+                // those with desc <= 0 are cleared in place.  Pass B: roots, range test and running minimum
+                // (sphere.cpp:27-50, hittablelist.cpp:21-29) for what is left, in ascending index order.
+                // Splitting keeps the square root and the two divisions out of the long first loop, where
+                // some lane of the wave would otherwise need them on every trip.
+                uint32_t nzb = 0u;
+                {
+                    uint32_t cand = 0u, keep = 0u; int cbase = 0, w = -1;
+                    for (;;) {
+                        if (cand == 0u) {
+                            if (w >= 0) { mask_words[w * 64] = keep; if (keep) nzb |= 0x80000000u >> w; }
+                            if (nz == 0u) break;
+                            w = __clz((int)nz);
+                            nz &= ~(0x80000000u >> w);
+                            cand = mask_words[w * 64];
+                            keep = 0u;
+                            cbase = sbase + (w << 5);
+                        }
+                        const int jj = __clz((int)cand);
+                        const uint32_t bit = 0x80000000u >> jj;
+                        cand &= ~bit;
+                        const int k = cbase + jj;
+                        if (k < a.n) {
+                            const float4 g = kLds ? s_geom[k] : a.geom[k];
+                            const V3 oc = ray.o - mk(g.x, g.y, g.z);
+                            const float b = dot(oc, ray.d);
+                            const float cc = dot(oc, oc) - g.w;
+                            const float desc = b * b - qa * cc;
+                            if (desc > 0.0f) keep |= bit;
+                        }
                     }
-                    const int jj = __clz((int)cand);
-                    cand &= ~(0x80000000u >> jj);
-                    const int k = cbase + jj;
-                    if (k < a.n) {
+                }
+                SECTION_MARK(2);
+                {
+                    uint32_t cand = 0u; int cbase = 0;
+                    for (;;) {
+                        if (cand == 0u) {
+                            if (nzb == 0u) break;
+                            const int w = __clz((int)nzb);
+                            nzb &= ~(0x80000000u >> w);
+                            cand = mask_words[w * 64];
+                            cbase = sbase + (w << 5);
+                        }
+                        const int jj = __clz((int)cand);
+                        cand &= ~(0x80000000u >> jj);
+                        const int k = cbase + jj;
                         const float4 g = kLds ? s_geom[k] : a.geom[k];
                         const V3 oc = ray.o - mk(g.x, g.y, g.z);
                         const float b = dot(oc, ray.d);
                         const float cc = dot(oc, oc) - g.w;
                         const float desc = b * b - qa * cc;
-                        if (desc > 0.0f) {
-                            const float sq = sqrtf(desc);
-                            float temp = (-b - sq) / qa;
-                            if (!(temp < closest && temp > a.tmin)) temp = (-b + sq) / qa;
-                            if (temp < closest && temp > a.tmin) { closest = temp; hit = k; }
-                        }
+                        const float sq = sqrtf(desc);
+                        float temp = (-b - sq) / qa;
+                        if (!(temp < closest && temp > a.tmin)) temp = (-b + sq) / qa;
+                        if (temp < closest && temp > a.tmin) { closest = temp; hit = k; }
                     }
                 }
                 SECTION_MARK(3);
