@@ -194,6 +194,7 @@ struct TraceArgs {
     int tiles_x; uint32_t Q;              // padded pixel count = tiles * 64
     int s_begin, s_count;                 // sample batch
     uint32_t total_items;                 // Q * s_count  (< 2^31)
+    int chunk_items;                      // items a wave reserves per atomic: a multiple of 64, at most kChunkItems
     float* samples;                       // [total_items][3]
     unsigned long long* ray_counter;
     unsigned int* work_counter;
@@ -259,11 +260,11 @@ __global__ void __launch_bounds__(kTraceBlock) k_trace(const TraceArgs a)
         while (need != 0ull && !(exhausted && pool_next == pool_end)) {
             if (pool_next == pool_end) {
                 unsigned int g = 0;
-                if (lane == 0) g = atomicAdd(a.work_counter, (unsigned int)kChunkItems);
+                if (lane == 0) g = atomicAdd(a.work_counter, (unsigned int)a.chunk_items);
                 g = __builtin_amdgcn_readfirstlane(g);
                 if (g >= a.total_items) { exhausted = true; break; }
                 pool_next = g; pool_base = g;
-                pool_end = (a.total_items - g < (uint32_t)kChunkItems) ? a.total_items : g + kChunkItems;
+                pool_end = (a.total_items - g < (uint32_t)a.chunk_items) ? a.total_items : g + (uint32_t)a.chunk_items;
                 // Generate the camera rays of the whole chunk now, all lanes busy, into this wave's staging
                 // rows in HBM; handing an item to a lane later is then eight loads.  (Generating on demand
                 // ran this code on every trip of the main loop for the third of the lanes that had finished.)
@@ -854,7 +855,13 @@ int rt_render_device(rt_context* ctx, const rt_params* p, float* d_rgb_mean, int
             a.samples = ctx->d_samples; a.ray_counter = ctx->d_rays; a.work_counter = ctx->d_work;
             a.stacks = ctx->d_stacks; a.stack_stride = (uint32_t)ctx->stacks_lanes; a.staging = ctx->d_staging;
             HIP_TRY(ctx, hipMemsetAsync(ctx->d_work, 0, sizeof(unsigned int), st));
-            uint64_t want_blocks = ((uint64_t)a.total_items + kChunkItems * (kTraceBlock / 64) - 1) / (kChunkItems * (kTraceBlock / 64));
+            // small jobs take smaller chunks so that every resident wave gets several (tail balance)
+            const uint64_t resident_waves = (uint64_t)ctx->num_cu * bpc * (kTraceBlock / 64);
+            uint64_t chunk = (uint64_t)a.total_items / (resident_waves * 16) / 64 * 64;
+            const uint64_t floor_items = (32768ull / (uint64_t)ctx->n_pad + 63) / 64 * 64;     // tiny scenes: keep per-chunk work above the hand-out overhead
+            if (chunk < floor_items) chunk = floor_items;
+            a.chunk_items = (int)(chunk < 64 ? 64 : (chunk > (uint64_t)kChunkItems ? (uint64_t)kChunkItems : chunk));
+            uint64_t want_blocks = ((uint64_t)a.total_items + (uint64_t)a.chunk_items * (kTraceBlock / 64) - 1) / ((uint64_t)a.chunk_items * (kTraceBlock / 64));
             const uint64_t cap_blocks = (uint64_t)ctx->num_cu * bpc;
             const dim3 grid((unsigned)(want_blocks < cap_blocks ? want_blocks : cap_blocks)), block(kTraceBlock);
             if (lds && plane) hipLaunchKernelGGL((k_trace<true, true>), grid, block, shmem, st, a);
