@@ -218,7 +218,7 @@ static constexpr int kSuperChunkWords = 16;                     // 32-sphere mas
 static constexpr float kRaySlack = 160.0f * 5.9604645e-08f;   // per-ray slack, relative to |o|^2
 static constexpr float kPlaneRaySlack = 128.0f * 5.9604645e-08f;
 
-template <bool kLds, bool kPlane>
+template <bool kLds, bool kPlane, bool kRecLds = false>
 __global__ void __launch_bounds__(kTraceBlock) k_trace(const TraceArgs a)
 {
     extern __shared__ float4 smem[];
@@ -229,10 +229,15 @@ __global__ void __launch_bounds__(kTraceBlock) k_trace(const TraceArgs a)
     if (kLds) {
         for (int i = threadIdx.x; i < a.n; i += kTraceBlock) { s_geom[i] = a.geom[i]; s_mat[i] = a.mat[i]; s_aux[i] = a.aux[i]; }
     }
-    __syncthreads();
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     // Per-lane filter masks of one super-chunk: word w of lane l at mask_words[w * 64] (lanes contiguous).
-    uint32_t* mask_words = reinterpret_cast<uint32_t*>(reinterpret_cast<char*>(smem) + (kLds ? (size_t)a.n * kLdsBytesPerSphere : 0)) + (size_t)wave * kSuperChunkWords * 64 + lane;
+    char* lds_after_scene = reinterpret_cast<char*>(smem) + (kLds ? (size_t)a.n * kLdsBytesPerSphere : 0);
+    uint32_t* mask_words = reinterpret_cast<uint32_t*>(lds_after_scene) + (size_t)wave * kSuperChunkWords * 64 + lane;
+    // Measurement variant (kRecLds): plane-filter records mirrored in LDS and read by broadcast ds_read_b128
+    // instead of by scalar load.
+    float4* s_prec = reinterpret_cast<float4*>(lds_after_scene + (size_t)(kTraceBlock / 64) * kSuperChunkWords * 64 * sizeof(uint32_t));
+    if (kRecLds) { for (int i = threadIdx.x; i < a.n_pad; i += kTraceBlock) s_prec[i] = a.prec[i]; }
+    __syncthreads();
     // The recursion's attenuation chain is replayed innermost-first when a path reaches the sky, so
     // each lane keeps the indices of the spheres it bounced off.  One 2-byte store per bounce and a
     // short read-back per finished path: kept in HBM so that LDS does not limit occupancy (packing the
@@ -364,9 +369,11 @@ __global__ void __launch_bounds__(kTraceBlock) k_trace(const TraceArgs a)
                 for (int jj = 0; jj < kCount; ++jj) {
                     float sgn;
                     if (kPlane) {
-                        const f4v f = prec_k[base + jj];
-                        const float pu = fmaf(f.x, ux, fmaf(f.y, uz, nou));
-                        sgn = s_ray - fmaf(pu, pu, f.z);
+                        float fx, fy, fz;
+                        if (kRecLds) { const float4 f = s_prec[base + jj]; fx = f.x; fy = f.y; fz = f.z; }
+                        else { const f4v f = prec_k[base + jj]; fx = f.x; fy = f.y; fz = f.z; }
+                        const float pu = fmaf(fx, ux, fmaf(fy, uz, nou));
+                        sgn = s_ray - fmaf(pu, pu, fz);
                     } else {
                         const f4v f = frec_k[base + jj];
                         const float b = fmaf(f.x, hx, fmaf(f.y, hy, fmaf(f.z, hz, nod)));
@@ -588,12 +595,13 @@ struct rt_context {
     float4* d_geom = nullptr; float4* d_mat = nullptr; Aux* d_aux = nullptr; int n = 0;
     float4* d_frec = nullptr; float4* d_prec = nullptr; float plane_s0 = 0.0f; int n_pad = 0;
     bool plane_filter = true;
+    bool records_in_lds = false;      // measurement variant, RT_AMD_RECORDS=lds
     float* d_samples = nullptr; size_t samples_bytes = 0;      // sample buffer of the persistent megakernel
     float* d_accum = nullptr; size_t accum_bytes = 0;          // running per-pixel sums across sample batches
     unsigned int* d_work = nullptr;
     uint16_t* d_stacks = nullptr; size_t stacks_lanes = 0;
     float* d_staging = nullptr;
-    int num_cu = 0; int trace_blocks_per_cu[4] = { 0, 0, 0, 0 };
+    int num_cu = 0; int trace_blocks_per_cu[5] = { 0, 0, 0, 0, 0 };
     bool have_camera = false; CameraD cam{};
     unsigned long long* d_rays = nullptr;
     hipEvent_t ev0 = nullptr, ev1 = nullptr; hipStream_t last_stream = nullptr; bool pending = false;
@@ -673,6 +681,7 @@ int rt_create(int device_ordinal, rt_context** out)
     ctx->device = device_ordinal;
     // RT_AMD_FILTER=disc selects the full-discriminant filter instead of the plane filter (A/B runs).
     { const char* f = getenv("RT_AMD_FILTER"); ctx->plane_filter = !(f && strcmp(f, "disc") == 0); }
+    { const char* f = getenv("RT_AMD_RECORDS"); ctx->records_in_lds = (f && strcmp(f, "lds") == 0); }
     hipError_t e = hipSetDevice(device_ordinal);
     if (e == hipSuccess) e = hipMalloc(&ctx->d_rays, sizeof(unsigned long long));
     if (e == hipSuccess) e = hipMalloc(&ctx->d_work, sizeof(unsigned int));
@@ -825,12 +834,13 @@ int rt_render_device(rt_context* ctx, const rt_params* p, float* d_rgb_mean, int
             HIP_TRY(ctx, hipMalloc(&ctx->d_accum, Q * 12)); ctx->accum_bytes = Q * 12;
         }
         const bool lds = ctx->n <= kMaxLdsSpheres;
-        const size_t shmem = (lds ? (size_t)ctx->n * kLdsBytesPerSphere : 0) + (size_t)(kTraceBlock / 64) * kSuperChunkWords * 64 * sizeof(uint32_t);
         const bool plane = ctx->plane_filter;
-        int& bpc = ctx->trace_blocks_per_cu[(lds ? 1 : 0) + (plane ? 2 : 0)];
+        const bool reclds = ctx->records_in_lds && lds && plane && ctx->n_pad <= 2048;
+        const size_t shmem = (lds ? (size_t)ctx->n * kLdsBytesPerSphere : 0) + (size_t)(kTraceBlock / 64) * kSuperChunkWords * 64 * sizeof(uint32_t) + (reclds ? (size_t)ctx->n_pad * sizeof(float4) : 0);
+        int& bpc = ctx->trace_blocks_per_cu[reclds ? 4 : (lds ? 1 : 0) + (plane ? 2 : 0)];
         if (bpc == 0) {
             int nb = 0;
-            auto kern = lds ? (plane ? k_trace<true, true> : k_trace<true, false>) : (plane ? k_trace<false, true> : k_trace<false, false>);
+            auto kern = reclds ? k_trace<true, true, true> : lds ? (plane ? k_trace<true, true> : k_trace<true, false>) : (plane ? k_trace<false, true> : k_trace<false, false>);
             hipError_t e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, kern, kTraceBlock, shmem);
             if (e != hipSuccess || nb <= 0) nb = 1;
             bpc = nb;
@@ -864,7 +874,8 @@ int rt_render_device(rt_context* ctx, const rt_params* p, float* d_rgb_mean, int
             uint64_t want_blocks = ((uint64_t)a.total_items + (uint64_t)a.chunk_items * (kTraceBlock / 64) - 1) / ((uint64_t)a.chunk_items * (kTraceBlock / 64));
             const uint64_t cap_blocks = (uint64_t)ctx->num_cu * bpc;
             const dim3 grid((unsigned)(want_blocks < cap_blocks ? want_blocks : cap_blocks)), block(kTraceBlock);
-            if (lds && plane) hipLaunchKernelGGL((k_trace<true, true>), grid, block, shmem, st, a);
+            if (reclds) hipLaunchKernelGGL((k_trace<true, true, true>), grid, block, shmem, st, a);
+            else if (lds && plane) hipLaunchKernelGGL((k_trace<true, true>), grid, block, shmem, st, a);
             else if (lds) hipLaunchKernelGGL((k_trace<true, false>), grid, block, shmem, st, a);
             else if (plane) hipLaunchKernelGGL((k_trace<false, true>), grid, block, shmem, st, a);
             else hipLaunchKernelGGL((k_trace<false, false>), grid, block, shmem, st, a);
