@@ -251,6 +251,28 @@ def test_stress_scene_rows_match_oracle(rt):
     assert same(both[0], both[1])
 
 
+def test_filter_variants_agree(rt, monkeypatch):
+    """The plane pre-filter (default) and the full-discriminant filter are both conservative: same image,
+    same ray count as the literal kernel.  Near the horizon the reference's own discriminant rounding lets it
+    hit spheres whose centre is up to 1e-4 farther than r from the ray; the slack of both filters covers it."""
+    import raytracing_amd._lib as L
+    imgs = {}
+    for filt in ("plane", "disc"):
+        monkeypatch.setenv("RT_AMD_FILTER", filt)
+        r2 = R.Renderer(0)
+        r2.upload_scene(R.final_scene_table())
+        r2.set_camera(R.final_camera(1200, 800))
+        # rows 240..287: the horizon band where grazing hits occur
+        p = r2.params(1200, 800, 24, seed=0, band_rows=48, band_first=5, band_step=1000)
+        imgs[filt] = r2.render(p)[:3]
+        if filt == "plane":
+            imgs["literal"] = r2.render(r2.params(1200, 800, 24, seed=0, band_rows=48, band_first=5, band_step=1000, mode=R.MODE_PIXEL))[:3]
+        r2.close()
+    for k in ("plane", "disc"):
+        assert imgs[k][2] == imgs["literal"][2]
+        assert np.array_equal(imgs[k][0].view(np.uint32), imgs["literal"][0].view(np.uint32))
+
+
 def test_edge_cases(rt):
     rt.upload_scene(R.three_sphere_table())
     rt.set_camera(R.three_camera(7, 5))
