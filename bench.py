@@ -181,7 +181,7 @@ def main():
             "kernel_ms_mean": kms_mean, "kernel_ms_max": kms_max,
             "roofline": {"bound": "valu", "achieved": achieved, "peak": PEAK_FP32_VALU_TFLOPS, "unit": "TFLOP/s",
                          "frac": achieved / PEAK_FP32_VALU_TFLOPS, "traffic": None,
-                         "kernel": "k_render_mega", "flop_per_ray": flop_per_ray,
+                         "kernel": "k_trace", "flop_per_ray": flop_per_ray,
                          "note": "FP32 vector-ALU bound (HBM traffic and MFMA are not on this path); algorithmic flops = rays x (18 x spheres + 150)"},
         }
         if world == 1 and not args.no_cpu_baseline:
