@@ -203,13 +203,21 @@ struct TraceArgs {
 };
 
 // Diagnostic build (-DRT_SECTION_TIMERS): every wave accumulates s_memtime ticks per section of the
-// main loop into g_section_ticks.  Never enabled in the shipped library.
+// main loop into g_section_ticks.  Never enabled in the shipped library (mark() is empty there).
 #ifdef RT_SECTION_TIMERS
 __device__ unsigned long long g_section_ticks[8];
-#define SECTION_BEGIN() const unsigned long long t_sec0_ = __builtin_amdgcn_s_memtime()
-#define SECTION_MARK(idx) do { const unsigned long long t_now_ = __builtin_amdgcn_s_memtime(); sec_acc[idx] += t_now_ - t_last_; t_last_ = t_now_; } while (0)
+struct SecTimer {
+    unsigned long long acc[8]; unsigned long long last;
+    __device__ __forceinline__ void start() { for (int k = 0; k < 8; ++k) acc[k] = 0; last = __builtin_amdgcn_s_memtime(); }
+    __device__ __forceinline__ void mark(int idx) { const unsigned long long t = __builtin_amdgcn_s_memtime(); acc[idx] += t - last; last = t; }
+    __device__ __forceinline__ void flush(int lane) { if (lane == 0) for (int k = 0; k < 8; ++k) atomicAdd(&g_section_ticks[k], acc[k]); }
+};
 #else
-#define SECTION_MARK(idx) do { } while (0)
+struct SecTimer {
+    __device__ __forceinline__ void start() {}
+    __device__ __forceinline__ void mark(int) {}
+    __device__ __forceinline__ void flush(int) {}
+};
 #endif
 static constexpr int kChunkItems = 512;
 static constexpr int kTraceBlock = 512;         // 8 waves share one LDS copy of the scene records
@@ -217,6 +225,166 @@ __device__ __forceinline__ float staged_load(const float* p) { return __hip_atom
 static constexpr int kSuperChunkWords = 16;                     // 32-sphere mask words kept per lane between exact passes (512 spheres)
 static constexpr float kRaySlack = 160.0f * 5.9604645e-08f;   // per-ray slack, relative to |o|^2
 static constexpr float kPlaneRaySlack = 128.0f * 5.9604645e-08f;
+
+// ============================================================================ closest-hit sweep
+// HittableList::Hit (hittablelist.cpp:13-31) over Sphere::Hit (sphere.cpp:15-52) for one ray per lane,
+// brute force over all spheres, as filter + exact (see k_trace).  Shared by the persistent megakernel and
+// the wavefront intersect kernel.  mask_words: this lane's column of kSuperChunkWords LDS words.
+struct SweepScene {
+    const float4* frec;      // disc-filter records (cx, cy, cz, |c|^2 - r^2 - slack), padded to a multiple of 8
+    const float4* prec;      // plane-filter records (cx, cz, -(r^2 + slack_i), 0), same padding
+    float plane_s0;          // constant part of the plane filter's per-ray slack
+    const float4* geom;      // exact records in HBM (used when they are not mirrored in LDS)
+    int n, n_pad;
+};
+
+template <bool kLds, bool kPlane, bool kRecLds>
+__device__ __forceinline__ void closest_hit(const RayD& ray, float tmin, const SweepScene& sw, const float4* s_geom, const float4* s_prec,
+                                            uint32_t* mask_words, float& closest, int& hit, SecTimer& T)
+{
+                            // Per ray: unit direction (approximate is enough for a conservative test), -(o.d^), 2o,
+                // -|o|^2 (1 - slack).  Per sphere record (cx, cy, cz, k), k = |c|^2 - r^2 - slack_i:
+                //   b = c.d^ - o.d^            3 FMA      w = 2 o.c - |o|^2'        3 FMA
+                //   e = b*b + w                1 FMA      s = e - k                 1 SUB   -> sign bit
+                // s >= 0 is necessary for the reference's discriminant to be positive.
+                const float qa = dot(ray.d, ray.d);
+                const float rs = __frsqrt_rn(fmaf(ray.d.x, ray.d.x, fmaf(ray.d.y, ray.d.y, ray.d.z * ray.d.z)));
+                const float hx = ray.d.x * rs, hy = ray.d.y * rs, hz = ray.d.z * rs;
+                const float nod = -fmaf(ray.o.x, hx, fmaf(ray.o.y, hy, ray.o.z * hz));
+                const float p2x = 2.0f * ray.o.x, p2y = 2.0f * ray.o.y, p2z = 2.0f * ray.o.z;
+                const float oo = fmaf(ray.o.x, ray.o.x, fmaf(ray.o.y, ray.o.y, ray.o.z * ray.o.z));
+                const float noo = kRaySlack * oo - oo;
+                // Plane filter (kPlane): the vertical plane through the ray has a horizontal normal u perp d, so
+                // the signed distance of a centre to it is pu = cx*ux + cz*uz - o.u (2 FMA).  The reference
+                // accepts a sphere only if its discriminant b^2 - a c is positive, and in its float arithmetic
+                // that can happen for a line passing up to sqrt(r^2 + 32 ulp (|o-c|^2 + r^2)) from the centre,
+                // so the test is pu^2 - R_i <= S_ray with that allowance (and this form's own rounding) split
+                // into a per-sphere part R_i (host) and a per-ray part S_ray: 3 FMA + 1 SUB per pair.
+                float ux = 1.0f, uz = 0.0f, nou = 0.0f, s_ray = 0.0f;
+                if (kPlane) {
+                    const float h2 = fmaf(hx, hx, hz * hz);
+                    if (h2 > 1e-12f) { const float ih = __frsqrt_rn(h2); ux = hz * ih; uz = -hx * ih; }
+                    nou = -fmaf(ray.o.x, ux, ray.o.z * uz);
+                    s_ray = fmaf(kPlaneRaySlack, oo, sw.plane_s0);
+                }
+                            // Filter records are read through the constant address space: the index is wave-uniform,
+                // so each record arrives by scalar load in SGPRs and feeds the FMAs as a scalar operand.
+                typedef float f4v __attribute__((ext_vector_type(4)));
+                typedef const __attribute__((address_space(4))) f4v* ConstRec;
+                const ConstRec frec_k = (ConstRec)(sw.frec);
+                const ConstRec prec_k = (ConstRec)(sw.prec);
+
+                // Filter one 32-sphere chunk (or a shorter tail, a multiple of 8): kCount sign bits, left-aligned
+                // (bit 31 = first record of the chunk), 1 = rejected.
+                auto filter_bits = [&](int base, auto count_tag) -> uint32_t {
+                    constexpr int kCount = decltype(count_tag)::value;
+                    uint32_t mask = 0u;
+    #pragma unroll
+                    for (int jj = 0; jj < kCount; ++jj) {
+                        float sgn;
+                        if (kPlane) {
+                            float fx, fy, fz;
+                            if (kRecLds) { const float4 f = s_prec[base + jj]; fx = f.x; fy = f.y; fz = f.z; }
+                            else { const f4v f = prec_k[base + jj]; fx = f.x; fy = f.y; fz = f.z; }
+                            const float pu = fmaf(fx, ux, fmaf(fy, uz, nou));
+                            sgn = s_ray - fmaf(pu, pu, fz);
+                        } else {
+                            const f4v f = frec_k[base + jj];
+                            const float b = fmaf(f.x, hx, fmaf(f.y, hy, fmaf(f.z, hz, nod)));
+                            const float w = fmaf(f.x, p2x, fmaf(f.y, p2y, fmaf(f.z, p2z, noo)));
+                            const float e = fmaf(b, b, w);
+                            sgn = e - f.w;
+                        }
+                        mask = __builtin_amdgcn_alignbit(mask, __float_as_uint(sgn), 31);   // append sign bit
+                    }
+                    return mask;
+                };
+
+                T.mark(1);
+                // Super-chunks of up to 16 mask words (512 spheres).  The filter only stores each word and notes
+                // whether it has a survivor; afterwards one loop per lane walks its surviving bits in ascending
+                // sphere order and runs the exact test of sphere.cpp:15-52 with the shrinking upper bound of
+                // hittablelist.cpp:21-29 (unfused arithmetic).
+                for (int sbase = 0; sbase < sw.n_pad; sbase += 32 * kSuperChunkWords) {
+                    uint32_t nz = 0u;          // bit (31 - w) set: word w of this super-chunk has a survivor
+                    int words = 0;
+                    int base = sbase;
+                    const int send = (sw.n_pad - sbase < 32 * kSuperChunkWords) ? sw.n_pad : sbase + 32 * kSuperChunkWords;
+                    for (; base + 32 <= send; base += 32, ++words) {
+                        const uint32_t cand = ~filter_bits(base, std::integral_constant<int, 32>());
+                        mask_words[words * 64] = cand;
+                        nz = __builtin_amdgcn_alignbit(nz, cand | (0u - cand), 31);
+                    }
+                    if (base < send) {         // tail: 8, 16 or 24 records
+                        uint32_t m = 0u; int got = 0;
+                        for (; base < send; base += 8, got += 8) m = (m << 8) | filter_bits(base, std::integral_constant<int, 8>());
+                        const uint32_t cand = (~m) << (32 - got);
+                        mask_words[words * 64] = cand;
+                        nz = __builtin_amdgcn_alignbit(nz, cand | (0u - cand), 31);
+                        ++words;
+                    }
+                    nz <<= (32 - words);
+                    T.mark(1);
+                    // Pass A: exact discriminant of every survivor of the filter (sphere.cpp:17-25); the bits of
+                    // those with desc <= 0 are cleared in place.  Pass B: roots, range test and running minimum
+                    // (sphere.cpp:27-50, hittablelist.cpp:21-29) for what is left, in ascending index order.
+                    // Splitting keeps the square root and the two divisions out of the long first loop, where
+                    // some lane of the wave would otherwise need them on every trip.
+                    uint32_t nzb = 0u;
+                    {
+                        uint32_t cand = 0u, keep = 0u; int cbase = 0, w = -1;
+                        for (;;) {
+                            if (cand == 0u) {
+                                if (w >= 0) { mask_words[w * 64] = keep; if (keep) nzb |= 0x80000000u >> w; }
+                                if (nz == 0u) break;
+                                w = __clz((int)nz);
+                                nz &= ~(0x80000000u >> w);
+                                cand = mask_words[w * 64];
+                                keep = 0u;
+                                cbase = sbase + (w << 5);
+                            }
+                            const int jj = __clz((int)cand);
+                            const uint32_t bit = 0x80000000u >> jj;
+                            cand &= ~bit;
+                            const int k = cbase + jj;
+                            if (k < sw.n) {
+                                const float4 g = kLds ? s_geom[k] : sw.geom[k];
+                                const V3 oc = ray.o - mk(g.x, g.y, g.z);
+                                const float b = dot(oc, ray.d);
+                                const float cc = dot(oc, oc) - g.w;
+                                const float desc = b * b - qa * cc;
+                                if (desc > 0.0f) keep |= bit;
+                            }
+                        }
+                    }
+                    T.mark(2);
+                    {
+                        uint32_t cand = 0u; int cbase = 0;
+                        for (;;) {
+                            if (cand == 0u) {
+                                if (nzb == 0u) break;
+                                const int w = __clz((int)nzb);
+                                nzb &= ~(0x80000000u >> w);
+                                cand = mask_words[w * 64];
+                                cbase = sbase + (w << 5);
+                            }
+                            const int jj = __clz((int)cand);
+                            cand &= ~(0x80000000u >> jj);
+                            const int k = cbase + jj;
+                            const float4 g = kLds ? s_geom[k] : sw.geom[k];
+                            const V3 oc = ray.o - mk(g.x, g.y, g.z);
+                            const float b = dot(oc, ray.d);
+                            const float cc = dot(oc, oc) - g.w;
+                            const float desc = b * b - qa * cc;
+                            const float sq = sqrtf(desc);
+                            float temp = (-b - sq) / qa;
+                            if (!(temp < closest && temp > tmin)) temp = (-b + sq) / qa;
+                            if (temp < closest && temp > tmin) { closest = temp; hit = k; }
+                        }
+                    }
+                    T.mark(3);
+                }
+}
 
 template <bool kLds, bool kPlane, bool kRecLds = false>
 __global__ void __launch_bounds__(kTraceBlock) k_trace(const TraceArgs a)
@@ -254,10 +422,8 @@ __global__ void __launch_bounds__(kTraceBlock) k_trace(const TraceArgs a)
     float* staged = a.staging + ((size_t)blockIdx.x * (kTraceBlock / 64) + wave) * (8 * kChunkItems);
     bool exhausted = false;                    // wave-uniform
     const float fnx = (float)a.width, fny = (float)a.height;
-#ifdef RT_SECTION_TIMERS
-    unsigned long long sec_acc[8] = { 0, 0, 0, 0, 0, 0, 0, 0 };
-    unsigned long long t_last_ = __builtin_amdgcn_s_memtime();
-#endif
+    SecTimer T; T.start();
+    SweepScene sw; sw.frec = a.frec; sw.prec = a.prec; sw.plane_s0 = a.plane_s0; sw.geom = a.geom; sw.n = a.n; sw.n_pad = a.n_pad;
 
     for (;;) {
         // ---------------------------------------------------------------- hand out new items
@@ -319,158 +485,16 @@ __global__ void __launch_bounds__(kTraceBlock) k_trace(const TraceArgs a)
             // padding pixels leave their lane idle; they are re-served next trip, which is harmless
             if (want <= avail) break;
         }
-        SECTION_MARK(0);
+        T.mark(0);
         if (!__any(active)) {
             if (exhausted && pool_next == pool_end) break;
             continue;
         }
 
         if (active) {
-            // ------------------------------------------------------------ filter
-            // Per ray: unit direction (approximate is enough for a conservative test), -(o.d^), 2o,
-            // -|o|^2 (1 - slack).  Per sphere record (cx, cy, cz, k), k = |c|^2 - r^2 - slack_i:
-            //   b = c.d^ - o.d^            3 FMA      w = 2 o.c - |o|^2'        3 FMA
-            //   e = b*b + w                1 FMA      s = e - k                 1 SUB   -> sign bit
-            // s >= 0 is necessary for the reference's discriminant to be positive.
-            const float qa = dot(ray.d, ray.d);
-            const float rs = __frsqrt_rn(fmaf(ray.d.x, ray.d.x, fmaf(ray.d.y, ray.d.y, ray.d.z * ray.d.z)));
-            const float hx = ray.d.x * rs, hy = ray.d.y * rs, hz = ray.d.z * rs;
-            const float nod = -fmaf(ray.o.x, hx, fmaf(ray.o.y, hy, ray.o.z * hz));
-            const float p2x = 2.0f * ray.o.x, p2y = 2.0f * ray.o.y, p2z = 2.0f * ray.o.z;
-            const float oo = fmaf(ray.o.x, ray.o.x, fmaf(ray.o.y, ray.o.y, ray.o.z * ray.o.z));
-            const float noo = kRaySlack * oo - oo;
-            // Plane filter (kPlane): the vertical plane through the ray has a horizontal normal u perp d, so
-            // the signed distance of a centre to it is pu = cx*ux + cz*uz - o.u (2 FMA).  The reference
-            // accepts a sphere only if its discriminant b^2 - a c is positive, and in its float arithmetic
-            // that can happen for a line passing up to sqrt(r^2 + 32 ulp (|o-c|^2 + r^2)) from the centre,
-            // so the test is pu^2 - R_i <= S_ray with that allowance (and this form's own rounding) split
-            // into a per-sphere part R_i (host) and a per-ray part S_ray: 3 FMA + 1 SUB per pair.
-            float ux = 1.0f, uz = 0.0f, nou = 0.0f, s_ray = 0.0f;
-            if (kPlane) {
-                const float h2 = fmaf(hx, hx, hz * hz);
-                if (h2 > 1e-12f) { const float ih = __frsqrt_rn(h2); ux = hz * ih; uz = -hx * ih; }
-                nou = -fmaf(ray.o.x, ux, ray.o.z * uz);
-                s_ray = fmaf(kPlaneRaySlack, oo, a.plane_s0);
-            }
             float closest = FLT_MAX; int hit = -1;
-            // Filter records are read through the constant address space: the index is wave-uniform,
-            // so each record arrives by scalar load in SGPRs and feeds the FMAs as a scalar operand.
-            typedef float f4v __attribute__((ext_vector_type(4)));
-            typedef const __attribute__((address_space(4))) f4v* ConstRec;
-            const ConstRec frec_k = (ConstRec)(a.frec);
-            const ConstRec prec_k = (ConstRec)(a.prec);
-
-            // Filter one 32-sphere chunk (or a shorter tail, a multiple of 8): kCount sign bits, left-aligned
-            // (bit 31 = first record of the chunk), 1 = rejected.
-            auto filter_bits = [&](int base, auto count_tag) -> uint32_t {
-                constexpr int kCount = decltype(count_tag)::value;
-                uint32_t mask = 0u;
-#pragma unroll
-                for (int jj = 0; jj < kCount; ++jj) {
-                    float sgn;
-                    if (kPlane) {
-                        float fx, fy, fz;
-                        if (kRecLds) { const float4 f = s_prec[base + jj]; fx = f.x; fy = f.y; fz = f.z; }
-                        else { const f4v f = prec_k[base + jj]; fx = f.x; fy = f.y; fz = f.z; }
-                        const float pu = fmaf(fx, ux, fmaf(fy, uz, nou));
-                        sgn = s_ray - fmaf(pu, pu, fz);
-                    } else {
-                        const f4v f = frec_k[base + jj];
-                        const float b = fmaf(f.x, hx, fmaf(f.y, hy, fmaf(f.z, hz, nod)));
-                        const float w = fmaf(f.x, p2x, fmaf(f.y, p2y, fmaf(f.z, p2z, noo)));
-                        const float e = fmaf(b, b, w);
-                        sgn = e - f.w;
-                    }
-                    mask = __builtin_amdgcn_alignbit(mask, __float_as_uint(sgn), 31);   // append sign bit
-                }
-                return mask;
-            };
-
-            SECTION_MARK(1);
-            // Super-chunks of up to 16 mask words (512 spheres).  The filter only stores each word and notes
-            // whether it has a survivor; afterwards one loop per lane walks its surviving bits in ascending
-            // sphere order and runs the exact test of sphere.cpp:15-52 with the shrinking upper bound of
-            // hittablelist.cpp:21-29 (unfused arithmetic).
-            for (int sbase = 0; sbase < a.n_pad; sbase += 32 * kSuperChunkWords) {
-                uint32_t nz = 0u;          // bit (31 - w) set: word w of this super-chunk has a survivor
-                int words = 0;
-                int base = sbase;
-                const int send = (a.n_pad - sbase < 32 * kSuperChunkWords) ? a.n_pad : sbase + 32 * kSuperChunkWords;
-                for (; base + 32 <= send; base += 32, ++words) {
-                    const uint32_t cand = ~filter_bits(base, std::integral_constant<int, 32>());
-                    mask_words[words * 64] = cand;
-                    nz = __builtin_amdgcn_alignbit(nz, cand | (0u - cand), 31);
-                }
-                if (base < send) {         // tail: 8, 16 or 24 records
-                    uint32_t m = 0u; int got = 0;
-                    for (; base < send; base += 8, got += 8) m = (m << 8) | filter_bits(base, std::integral_constant<int, 8>());
-                    const uint32_t cand = (~m) << (32 - got);
-                    mask_words[words * 64] = cand;
-                    nz = __builtin_amdgcn_alignbit(nz, cand | (0u - cand), 31);
-                    ++words;
-                }
-                nz <<= (32 - words);
-                SECTION_MARK(1);
-                // Pass A: exact discriminant of every survivor of the filter (sphere.cpp:17-25); the bits of
-                // those with desc <= 0 are cleared in place.  Pass B: roots, range test and running minimum
-                // (sphere.cpp:27-50, hittablelist.cpp:21-29) for what is left, in ascending index order.
-                // Splitting keeps the square root and the two divisions out of the long first loop, where
-                // some lane of the wave would otherwise need them on every trip.
-                uint32_t nzb = 0u;
-                {
-                    uint32_t cand = 0u, keep = 0u; int cbase = 0, w = -1;
-                    for (;;) {
-                        if (cand == 0u) {
-                            if (w >= 0) { mask_words[w * 64] = keep; if (keep) nzb |= 0x80000000u >> w; }
-                            if (nz == 0u) break;
-                            w = __clz((int)nz);
-                            nz &= ~(0x80000000u >> w);
-                            cand = mask_words[w * 64];
-                            keep = 0u;
-                            cbase = sbase + (w << 5);
-                        }
-                        const int jj = __clz((int)cand);
-                        const uint32_t bit = 0x80000000u >> jj;
-                        cand &= ~bit;
-                        const int k = cbase + jj;
-                        if (k < a.n) {
-                            const float4 g = kLds ? s_geom[k] : a.geom[k];
-                            const V3 oc = ray.o - mk(g.x, g.y, g.z);
-                            const float b = dot(oc, ray.d);
-                            const float cc = dot(oc, oc) - g.w;
-                            const float desc = b * b - qa * cc;
-                            if (desc > 0.0f) keep |= bit;
-                        }
-                    }
-                }
-                SECTION_MARK(2);
-                {
-                    uint32_t cand = 0u; int cbase = 0;
-                    for (;;) {
-                        if (cand == 0u) {
-                            if (nzb == 0u) break;
-                            const int w = __clz((int)nzb);
-                            nzb &= ~(0x80000000u >> w);
-                            cand = mask_words[w * 64];
-                            cbase = sbase + (w << 5);
-                        }
-                        const int jj = __clz((int)cand);
-                        cand &= ~(0x80000000u >> jj);
-                        const int k = cbase + jj;
-                        const float4 g = kLds ? s_geom[k] : a.geom[k];
-                        const V3 oc = ray.o - mk(g.x, g.y, g.z);
-                        const float b = dot(oc, ray.d);
-                        const float cc = dot(oc, oc) - g.w;
-                        const float desc = b * b - qa * cc;
-                        const float sq = sqrtf(desc);
-                        float temp = (-b - sq) / qa;
-                        if (!(temp < closest && temp > a.tmin)) temp = (-b + sq) / qa;
-                        if (temp < closest && temp > a.tmin) { closest = temp; hit = k; }
-                    }
-                }
-                SECTION_MARK(3);
-            }
-            SECTION_MARK(4);
+            closest_hit<kLds, kPlane, kRecLds>(ray, a.tmin, sw, s_geom, s_prec, mask_words, closest, hit, T);
+            T.mark(4);
             ++rays;
             // ------------------------------------------------------------ shade (main.cpp:13-39)
             V3 sample = mk(0.0f, 0.0f, 0.0f); bool done = true;
@@ -480,7 +504,7 @@ __global__ void __launch_bounds__(kTraceBlock) k_trace(const TraceArgs a)
                 const Aux x = kLds ? s_aux[hit] : a.aux[hit];
                 const V3 p = ray.o + closest * ray.d;
                 const V3 nrm = (p - mk(g.x, g.y, g.z)) / x.radius;
-                SECTION_MARK(5);
+                T.mark(5);
                 if (depth < a.max_depth) {
                     V3 att; RayD out;
                     U.slot(pix, smp, (uint32_t)depth + 1u);
@@ -488,7 +512,7 @@ __global__ void __launch_bounds__(kTraceBlock) k_trace(const TraceArgs a)
                         stack[(size_t)depth * sstride] = (uint16_t)hit; ++depth; ray = out; done = false;
                     }
                 }
-                SECTION_MARK(6);
+                T.mark(6);
             } else {
                 sample = sky(ray.d);
                 for (int k = depth - 1; k >= 0; --k) {
@@ -502,12 +526,10 @@ __global__ void __launch_bounds__(kTraceBlock) k_trace(const TraceArgs a)
                 o[0] = sample.x; o[1] = sample.y; o[2] = sample.z;
                 active = false;
             }
-            SECTION_MARK(7);
+            T.mark(7);
         }
     }
-#ifdef RT_SECTION_TIMERS
-    if (lane == 0) for (int k = 0; k < 8; ++k) atomicAdd(&g_section_ticks[k], sec_acc[k]);
-#endif
+    T.flush(lane);
     // one atomic per wave
     for (int off = 32; off > 0; off >>= 1) rays += __shfl_down(rays, off);
     if (lane == 0 && rays) atomicAdd(a.ray_counter, (unsigned long long)rays);
