@@ -78,6 +78,7 @@ def main():
     ap.add_argument("--band-rows", type=int, default=8)
     ap.add_argument("--seed", type=int, default=0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--mode", default="megakernel", choices=["megakernel", "wavefront", "pixel"])
     ap.add_argument("--rehearse-on-one-gpu", action="store_true",
                     help="debug: all ranks share GPU 0 and gather over gloo (RCCL refuses two ranks on one device)")
     args = ap.parse_args()
@@ -118,7 +119,8 @@ def main():
     n_spheres = len(table)
 
     band = args.band_rows
-    p = rt.params(width, height, spp, seed=args.seed, band_rows=band, band_first=rank, band_step=world)
+    mode = {"megakernel": R.MODE_MEGAKERNEL, "wavefront": R.MODE_WAVEFRONT, "pixel": R.MODE_PIXEL}[args.mode]
+    p = rt.params(width, height, spp, seed=args.seed, band_rows=band, band_first=rank, band_step=world, mode=mode)
     pad = rdist.max_owned_rows(height, band, world)
     out = torch.zeros((pad, width, 3), dtype=torch.int32, device=dev)
     idx = rdist.row_index(height, band, world, dev) if world > 1 else None
@@ -176,12 +178,12 @@ def main():
                        if scene_name == "final" else (f"{args.workload}: synthetic {n_spheres}-sphere grid scene, {width}x{height}, {spp} spp, max depth 50"
                                                       if scene_name == "grid20k" else f"{args.workload}: three-sphere material scene, {width}x{height}, {spp} spp"),
                        "band_rows": band, "partition": f"interleaved row bands over {world} GPU(s), one RCCL gather to rank 0" if world > 1 else "single GPU",
-                       "seed": args.seed, "mode": "megakernel"},
+                       "seed": args.seed, "mode": args.mode},
             "msamples_per_s": samples / elapsed / 1e6, "rays_per_sample": total_rays / samples,
             "kernel_ms_mean": kms_mean, "kernel_ms_max": kms_max,
             "roofline": {"bound": "valu", "achieved": achieved, "peak": PEAK_FP32_VALU_TFLOPS, "unit": "TFLOP/s",
                          "frac": achieved / PEAK_FP32_VALU_TFLOPS, "traffic": None,
-                         "kernel": "k_trace", "flop_per_ray": flop_per_ray,
+                         "kernel": {"megakernel": "k_trace", "wavefront": "k_wf_intersect + k_wf_shade", "pixel": "k_render_mega"}[args.mode], "flop_per_ray": flop_per_ray,
                          "note": "FP32 vector-ALU bound (HBM traffic and MFMA are not on this path); algorithmic flops = rays x (18 x spheres + 150)"},
         }
         if world == 1 and not args.no_cpu_baseline:

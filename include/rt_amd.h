@@ -38,7 +38,9 @@ enum rt_mode {
     RT_MODE_MEGAKERNEL = 0,   /* persistent waves; a lane whose path ends takes the next (pixel, sample)
                                  item at once (ballot + prefix count); conservative FMA filter over the
                                  spheres, exact test on the survivors */
-    RT_MODE_WAVEFRONT = 1,    /* ray queues in HBM compacted with wave ballot/prefix counts */
+    RT_MODE_WAVEFRONT = 1,    /* a pool of path slots and ray queues in HBM: one intersect and one shade
+                                 kernel per bounce, surviving slots compacted with wave ballot/prefix counts;
+                                 the host reads the live count every 8 bounces, so the call synchronises */
     RT_MODE_PIXEL = 2         /* plain kernel: one lane per pixel, literal per-sphere test, scene in LDS */
 };
 

@@ -386,6 +386,63 @@ __device__ __forceinline__ void closest_hit(const RayD& ray, float tmin, const S
                 }
 }
 
+// ============================================================================ shading step of Color()
+// One level of the recursion main.cpp:13-39 for a ray whose closest hit is known.  Returns true when the
+// path has ended (sample = its radiance); otherwise ray/depth are advanced and the hit index is pushed on
+// the lane's stack (element k at stack[k * sstride]).
+template <bool kLds>
+__device__ __forceinline__ bool shade_step(RayD& ray, int& depth, float closest, int hit, uint32_t pix, uint32_t smp, int max_depth,
+                                           KeyedUniforms& U, const float4* s_geom, const float4* s_mat, const Aux* s_aux,
+                                           const float4* g_geom, const float4* g_mat, const Aux* g_aux,
+                                           uint16_t* stack, size_t sstride, V3& sample, SecTimer& T)
+{
+    sample = mk(0.0f, 0.0f, 0.0f);
+    bool done = true;
+    if (hit >= 0) {
+        const float4 g = kLds ? s_geom[hit] : g_geom[hit];
+        const float4 m = kLds ? s_mat[hit] : g_mat[hit];
+        const Aux x = kLds ? s_aux[hit] : g_aux[hit];
+        const V3 p = ray.o + closest * ray.d;
+        const V3 nrm = (p - mk(g.x, g.y, g.z)) / x.radius;
+        T.mark(5);
+        if (depth < max_depth) {
+            V3 att; RayD out;
+            U.slot(pix, smp, (uint32_t)depth + 1u);
+            if (scatter(x.type, mk(m.x, m.y, m.z), m.w, ray, p, nrm, U, att, out)) {
+                stack[(size_t)depth * sstride] = (uint16_t)hit; ++depth; ray = out; done = false;
+            }
+        }
+        T.mark(6);
+    } else {
+        sample = sky(ray.d);
+        for (int k = depth - 1; k >= 0; --k) {
+            const int h = stack[(size_t)k * sstride];
+            const float4 m = kLds ? s_mat[h] : g_mat[h];
+            sample = mk(m.x, m.y, m.z) * sample;
+        }
+    }
+    return done;
+}
+
+// Work item -> (pixel key, sample, pixel coordinates).  Items are numbered sample-major over 8x8 tiles:
+// item = s_rel * Q + q, q = tile * 64 + row_in_tile * 8 + col_in_tile.  Returns false for the padding
+// pixels of edge tiles.
+struct ItemGeometry { int width, height, band_rows, band_first, band_step, owned_rows, tiles_x; uint32_t Q; int s_begin; };
+__device__ __forceinline__ bool decode_item(const ItemGeometry& ig, uint32_t item, uint32_t& pix, uint32_t& smp, int& i, int& j)
+{
+    const uint32_t s_rel = item / ig.Q, q = item - s_rel * ig.Q;
+    const uint32_t tile = q >> 6, l = q & 63u;
+    const int ty = (int)(tile / (uint32_t)ig.tiles_x), tx = (int)(tile - (uint32_t)ty * (uint32_t)ig.tiles_x);
+    i = tx * 8 + (int)(l & 7u);
+    const int r = ty * 8 + (int)(l >> 3);
+    const int y = owned_row_to_y2(ig.band_rows, ig.band_first, ig.band_step, r < ig.owned_rows ? r : 0);
+    if (!(i < ig.width && r < ig.owned_rows && y < ig.height)) return false;
+    j = ig.height - 1 - y;
+    pix = (uint32_t)j * (uint32_t)ig.width + (uint32_t)i;
+    smp = (uint32_t)ig.s_begin + s_rel;
+    return true;
+}
+
 template <bool kLds, bool kPlane, bool kRecLds = false>
 __global__ void __launch_bounds__(kTraceBlock) k_trace(const TraceArgs a)
 {
@@ -423,6 +480,8 @@ __global__ void __launch_bounds__(kTraceBlock) k_trace(const TraceArgs a)
     bool exhausted = false;                    // wave-uniform
     const float fnx = (float)a.width, fny = (float)a.height;
     SecTimer T; T.start();
+    ItemGeometry ig; ig.width = a.width; ig.height = a.height; ig.band_rows = a.band_rows; ig.band_first = a.band_first; ig.band_step = a.band_step;
+    ig.owned_rows = a.owned_rows; ig.tiles_x = a.tiles_x; ig.Q = a.Q; ig.s_begin = a.s_begin;
     SweepScene sw; sw.frec = a.frec; sw.prec = a.prec; sw.plane_s0 = a.plane_s0; sw.geom = a.geom; sw.n = a.n; sw.n_pad = a.n_pad;
 
     for (;;) {
@@ -440,19 +499,10 @@ __global__ void __launch_bounds__(kTraceBlock) k_trace(const TraceArgs a)
                 // rows in HBM; handing an item to a lane later is then eight loads.  (Generating on demand
                 // ran this code on every trip of the main loop for the third of the lanes that had finished.)
                 for (uint32_t it = g + (uint32_t)lane; it < pool_end; it += 64u) {
-                    const uint32_t s_rel = it / a.Q, q = it - s_rel * a.Q;
-                    const uint32_t tile = q >> 6, l = q & 63u;
-                    const int ty = (int)(tile / (uint32_t)a.tiles_x), tx = (int)(tile - (uint32_t)ty * (uint32_t)a.tiles_x);
-                    const int i = tx * 8 + (int)(l & 7u), r = ty * 8 + (int)(l >> 3);
-                    const int y = owned_row_to_y2(a.band_rows, a.band_first, a.band_step, r < a.owned_rows ? r : 0);
-                    uint32_t gp = 0xffffffffu, gs = 0u;
+                    uint32_t gp = 0xffffffffu, gs = 0u; int i = 0, j = 0;
                     RayD gr; gr.o = mk(0, 0, 0); gr.d = mk(0, 0, 0);
-                    if (i < a.width && r < a.owned_rows && y < a.height) {
-                        const int j = a.height - 1 - y;
-                        gp = (uint32_t)j * (uint32_t)a.width + (uint32_t)i;
-                        gs = (uint32_t)a.s_begin + s_rel;
-                        gr = camera_ray(a.cam, gp, gs, i, j, fnx, fny, a.k0, a.k1);
-                    }
+                    if (decode_item(ig, it, gp, gs, i, j)) gr = camera_ray(a.cam, gp, gs, i, j, fnx, fny, a.k0, a.k1);
+                    else gp = 0xffffffffu;
                     const uint32_t slot = it - g;
                     staged[0 * kChunkItems + slot] = gr.o.x; staged[1 * kChunkItems + slot] = gr.o.y; staged[2 * kChunkItems + slot] = gr.o.z;
                     staged[3 * kChunkItems + slot] = gr.d.x; staged[4 * kChunkItems + slot] = gr.d.y; staged[5 * kChunkItems + slot] = gr.d.z;
@@ -497,30 +547,8 @@ __global__ void __launch_bounds__(kTraceBlock) k_trace(const TraceArgs a)
             T.mark(4);
             ++rays;
             // ------------------------------------------------------------ shade (main.cpp:13-39)
-            V3 sample = mk(0.0f, 0.0f, 0.0f); bool done = true;
-            if (hit >= 0) {
-                const float4 g = kLds ? s_geom[hit] : a.geom[hit];
-                const float4 m = kLds ? s_mat[hit] : a.mat[hit];
-                const Aux x = kLds ? s_aux[hit] : a.aux[hit];
-                const V3 p = ray.o + closest * ray.d;
-                const V3 nrm = (p - mk(g.x, g.y, g.z)) / x.radius;
-                T.mark(5);
-                if (depth < a.max_depth) {
-                    V3 att; RayD out;
-                    U.slot(pix, smp, (uint32_t)depth + 1u);
-                    if (scatter(x.type, mk(m.x, m.y, m.z), m.w, ray, p, nrm, U, att, out)) {
-                        stack[(size_t)depth * sstride] = (uint16_t)hit; ++depth; ray = out; done = false;
-                    }
-                }
-                T.mark(6);
-            } else {
-                sample = sky(ray.d);
-                for (int k = depth - 1; k >= 0; --k) {
-                    const int h = stack[(size_t)k * sstride];
-                    const float4 m = kLds ? s_mat[h] : a.mat[h];
-                    sample = mk(m.x, m.y, m.z) * sample;
-                }
-            }
+            V3 sample;
+            const bool done = shade_step<kLds>(ray, depth, closest, hit, pix, smp, a.max_depth, U, s_geom, s_mat, s_aux, a.geom, a.mat, a.aux, stack, sstride, sample, T);
             if (done) {
                 float* o = a.samples + (size_t)item * 3;
                 o[0] = sample.x; o[1] = sample.y; o[2] = sample.z;
@@ -560,6 +588,140 @@ __global__ void __launch_bounds__(256) k_resolve(const ResolveArgs a)
     const size_t o = ((size_t)r * a.width + i) * 3;
     if (a.rgb_mean) { a.rgb_mean[o] = mr; a.rgb_mean[o + 1] = mg; a.rgb_mean[o + 2] = mb; }
     if (a.irgb) { a.irgb[o] = quantise(mr); a.irgb[o + 1] = quantise(mg); a.irgb[o + 2] = quantise(mb); }
+}
+
+// ============================================================================ wavefront mode
+// The same path tracer as three kernels over ray queues in HBM (mode RT_MODE_WAVEFRONT).  A pool of P path
+// slots holds one ray each; a queue lists the live slots.  Per bounce: k_wf_intersect runs the closest-hit
+// sweep for every queued ray (all lanes busy, nothing else in the kernel); k_wf_shade scatters or finishes
+// each ray, gives a finished slot the next (pixel, sample) item, and writes the surviving slot ids to the
+// next queue compacted with a wave ballot + prefix count and one atomic per wave.
+struct WfArgs {
+    SweepScene sw; const float4* mat; const Aux* aux;
+    CameraD cam; ItemGeometry ig;
+    int max_depth; float tmin; uint32_t k0, k1;
+    uint32_t total_items, P;
+    float* ray;                 // [6][P]  o.xyz, d.xyz
+    uint32_t* pixsmp;           // [3][P]  pixel key, sample, item
+    int* depth;                 // [P]
+    float* hit_t; int* hit_idx; // [P]
+    uint16_t* stacks;           // [RT_MAX_DEPTH][P]
+    const uint32_t* q_in; uint32_t* q_out; const uint32_t* n_in; uint32_t* n_out;
+    unsigned int* work_counter; unsigned long long* ray_counter;
+    float* samples;
+};
+
+__global__ void __launch_bounds__(256) k_wf_init(const WfArgs a)
+{
+    const uint32_t s = blockIdx.x * 256u + threadIdx.x;
+    const uint32_t first = a.P < a.total_items ? a.P : a.total_items;
+    if (s == 0) { *a.work_counter = first; }
+    if (s >= first) return;
+    uint32_t pix = 0, smp = 0; int i = 0, j = 0;
+    const bool ok = decode_item(a.ig, s, pix, smp, i, j);
+    // every slot starts live; a padding pixel becomes a ray that is retired (and replaced) by the first shade pass
+    RayD r; r.o = mk(0, 0, 0); r.d = mk(0, 0, 0);
+    if (ok) r = camera_ray(a.cam, pix, smp, i, j, (float)a.ig.width, (float)a.ig.height, a.k0, a.k1);
+    a.ray[0 * (size_t)a.P + s] = r.o.x; a.ray[1 * (size_t)a.P + s] = r.o.y; a.ray[2 * (size_t)a.P + s] = r.o.z;
+    a.ray[3 * (size_t)a.P + s] = r.d.x; a.ray[4 * (size_t)a.P + s] = r.d.y; a.ray[5 * (size_t)a.P + s] = r.d.z;
+    a.pixsmp[0 * (size_t)a.P + s] = ok ? pix : 0xffffffffu; a.pixsmp[1 * (size_t)a.P + s] = smp; a.pixsmp[2 * (size_t)a.P + s] = s;
+    a.depth[s] = 0;
+    a.q_out[s] = s;
+    if (s == 0) *a.n_out = first;
+}
+
+template <bool kLds, bool kPlane>
+__global__ void __launch_bounds__(kTraceBlock) k_wf_intersect(const WfArgs a)
+{
+    extern __shared__ float4 smem[];
+    float4* s_geom = smem;
+    if (kLds) { for (int i = threadIdx.x; i < a.sw.n; i += kTraceBlock) s_geom[i] = a.sw.geom[i]; }
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    uint32_t* mask_words = reinterpret_cast<uint32_t*>(reinterpret_cast<char*>(smem) + (kLds ? (size_t)a.sw.n * sizeof(float4) : 0)) + (size_t)wave * kSuperChunkWords * 64 + lane;
+    __syncthreads();
+    const uint32_t n_in = *a.n_in;
+    SecTimer T; T.start();
+    // grid-stride over the queue so that a block's LDS copy of the scene serves many rays
+    for (uint32_t e = blockIdx.x * (uint32_t)kTraceBlock + threadIdx.x; e < n_in; e += gridDim.x * (uint32_t)kTraceBlock) {
+        const uint32_t s = a.q_in[e];
+        RayD ray;
+        ray.o = mk(a.ray[0 * (size_t)a.P + s], a.ray[1 * (size_t)a.P + s], a.ray[2 * (size_t)a.P + s]);
+        ray.d = mk(a.ray[3 * (size_t)a.P + s], a.ray[4 * (size_t)a.P + s], a.ray[5 * (size_t)a.P + s]);
+        float closest = FLT_MAX; int hit = -1;
+        if (a.pixsmp[s] != 0xffffffffu) closest_hit<kLds, kPlane, false>(ray, a.tmin, a.sw, s_geom, nullptr, mask_words, closest, hit, T);
+        a.hit_t[s] = closest; a.hit_idx[s] = hit;
+    }
+}
+
+__global__ void __launch_bounds__(256) k_wf_shade(const WfArgs a)
+{
+    const int lane = threadIdx.x & 63;
+    const uint32_t n_in = *a.n_in;
+    const uint32_t e = blockIdx.x * 256u + threadIdx.x;
+    bool live = e < n_in;
+    bool traced = false;          // this lane's ray went through a closest-hit query
+    bool need = false, fresh = false;
+    V3 ray_o = mk(0, 0, 0), ray_d = mk(0, 0, 0); int depth_out = 0; uint32_t pix_out = 0, smp_out = 0;
+    uint32_t s = 0;
+    SecTimer T; T.start();
+    if (live) {
+        s = a.q_in[e];
+        RayD ray;
+        ray.o = mk(a.ray[0 * (size_t)a.P + s], a.ray[1 * (size_t)a.P + s], a.ray[2 * (size_t)a.P + s]);
+        ray.d = mk(a.ray[3 * (size_t)a.P + s], a.ray[4 * (size_t)a.P + s], a.ray[5 * (size_t)a.P + s]);
+        uint32_t pix = a.pixsmp[0 * (size_t)a.P + s], smp = a.pixsmp[1 * (size_t)a.P + s];
+        const uint32_t item = a.pixsmp[2 * (size_t)a.P + s];
+        int depth = a.depth[s];
+        bool done = true; V3 sample = mk(0, 0, 0);
+        KeyedUniforms U; U.k0 = a.k0; U.k1 = a.k1; U.slot(pix, smp, 0); U.cur = U4{ 0, 0, 0, 0 };
+        if (pix != 0xffffffffu) {
+            traced = true;
+            done = shade_step<false>(ray, depth, a.hit_t[s], a.hit_idx[s], pix, smp, a.max_depth, U, nullptr, nullptr, nullptr,
+                                     a.sw.geom, a.mat, a.aux, a.stacks + s, (size_t)a.P, sample, T);
+            if (done) { float* o = a.samples + (size_t)item * 3; o[0] = sample.x; o[1] = sample.y; o[2] = sample.z; }
+        }
+        need = done;
+        if (done) live = false;
+        ray_o = ray.o; ray_d = ray.d; depth_out = depth; pix_out = pix; smp_out = smp;
+    }
+    // A finished slot takes the next (pixel, sample) item.  Items are reserved per wave: ballot of the lanes
+    // that need one, one atomic for the whole wave, prefix rank per lane.  (One atomic per lane on the single
+    // counter word costs about a millisecond per pass at 8 M rays.)  Padding pixels of edge tiles are skipped
+    // by asking again.
+    uint32_t item_out = 0;
+    for (;;) {
+        const unsigned long long want = __ballot(need);
+        if (want == 0ull) break;
+        uint32_t base = 0;
+        if (lane == 0) base = atomicAdd(a.work_counter, (uint32_t)__popcll(want));
+        base = __builtin_amdgcn_readfirstlane(base);
+        if (need) {
+            const uint32_t it = base + __builtin_amdgcn_mbcnt_hi((uint32_t)(want >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)want, 0u));
+            int i = 0, j = 0;
+            if (it >= a.total_items) { need = false; }
+            else if (decode_item(a.ig, it, pix_out, smp_out, i, j)) {
+                const RayD r = camera_ray(a.cam, pix_out, smp_out, i, j, (float)a.ig.width, (float)a.ig.height, a.k0, a.k1);
+                ray_o = r.o; ray_d = r.d; depth_out = 0; item_out = it; live = true; need = false; fresh = true;
+            }
+        }
+    }
+    if (live) {
+        a.ray[0 * (size_t)a.P + s] = ray_o.x; a.ray[1 * (size_t)a.P + s] = ray_o.y; a.ray[2 * (size_t)a.P + s] = ray_o.z;
+        a.ray[3 * (size_t)a.P + s] = ray_d.x; a.ray[4 * (size_t)a.P + s] = ray_d.y; a.ray[5 * (size_t)a.P + s] = ray_d.z;
+        a.depth[s] = depth_out;
+        if (fresh) { a.pixsmp[0 * (size_t)a.P + s] = pix_out; a.pixsmp[1 * (size_t)a.P + s] = smp_out; a.pixsmp[2 * (size_t)a.P + s] = item_out; }
+    }
+    const unsigned long long did = __ballot(traced);
+    if (lane == 0 && did != 0ull) atomicAdd(a.ray_counter, (unsigned long long)__popcll(did));
+    // compaction: ballot of surviving lanes, prefix rank within the wave, one atomic per wave
+    const unsigned long long alive = __ballot(live);
+    if (alive != 0ull) {
+        uint32_t base = 0;
+        if (lane == 0) base = atomicAdd(a.n_out, (uint32_t)__popcll(alive));
+        base = __builtin_amdgcn_readfirstlane(base);
+        const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(alive >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)alive, 0u));
+        if (live) a.q_out[base + rank] = s;
+    }
 }
 
 // ============================================================================ unit-level kernels
@@ -623,6 +785,10 @@ struct rt_context {
     unsigned int* d_work = nullptr;
     uint16_t* d_stacks = nullptr; size_t stacks_lanes = 0;
     float* d_staging = nullptr;
+    // wavefront mode pool
+    uint32_t wf_P = 0; float* wf_ray = nullptr; uint32_t* wf_pixsmp = nullptr; int* wf_depth = nullptr; float* wf_hit_t = nullptr; int* wf_hit_idx = nullptr;
+    uint16_t* wf_stacks = nullptr; uint32_t* wf_q[2] = { nullptr, nullptr }; uint32_t* wf_n = nullptr;
+    int wf_blocks_per_cu[4] = { 0, 0, 0, 0 };
     int num_cu = 0; int trace_blocks_per_cu[5] = { 0, 0, 0, 0, 0 };
     bool have_camera = false; CameraD cam{};
     unsigned long long* d_rays = nullptr;
@@ -722,6 +888,8 @@ void rt_destroy(rt_context* ctx)
     if (ctx->pending) (void)hipStreamSynchronize(ctx->last_stream);
     (void)hipFree(ctx->d_geom); (void)hipFree(ctx->d_mat); (void)hipFree(ctx->d_aux); (void)hipFree(ctx->d_rays);
     (void)hipFree(ctx->d_frec); (void)hipFree(ctx->d_prec); (void)hipFree(ctx->d_samples); (void)hipFree(ctx->d_accum); (void)hipFree(ctx->d_work); (void)hipFree(ctx->d_stacks); (void)hipFree(ctx->d_staging);
+    (void)hipFree(ctx->wf_ray); (void)hipFree(ctx->wf_pixsmp); (void)hipFree(ctx->wf_depth); (void)hipFree(ctx->wf_hit_t); (void)hipFree(ctx->wf_hit_idx);
+    (void)hipFree(ctx->wf_stacks); (void)hipFree(ctx->wf_q[0]); (void)hipFree(ctx->wf_q[1]); (void)hipFree(ctx->wf_n);
     if (ctx->ev0) (void)hipEventDestroy(ctx->ev0);
     if (ctx->ev1) (void)hipEventDestroy(ctx->ev1);
     delete ctx;
@@ -818,7 +986,6 @@ int rt_render_device(rt_context* ctx, const rt_params* p, float* d_rgb_mean, int
     if (!ctx) return fail(nullptr, RT_ERR_INVALID, "rt_render_device: null context");
     if (!params_ok(p)) return fail(ctx, RT_ERR_INVALID, "rt_render_device: invalid parameters");
     if (!ctx->n || !ctx->have_camera) return fail(ctx, RT_ERR_STATE, "rt_render_device: scene and camera must be set first");
-    if (p->mode == RT_MODE_WAVEFRONT) return fail(ctx, RT_ERR_INVALID, "rt_render_device: wavefront mode is not built into this library");
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     hipStream_t st = static_cast<hipStream_t>(stream);
     const int owned = (int)rt_owned_rows(p);
@@ -878,6 +1045,72 @@ int rt_render_device(rt_context* ctx, const rt_params* p, float* d_rgb_mean, int
         }
         for (int bi = 0, s0 = 0; bi < batches; ++bi, s0 += s_per) {
             const int sc = (p->spp - s0 < s_per) ? p->spp - s0 : s_per;
+            if (p->mode == RT_MODE_WAVEFRONT) {
+                const uint32_t total = (uint32_t)(Q * sc);
+                const uint32_t P = total < (8u << 20) ? (total + 255u) / 256u * 256u : (8u << 20);
+                if (ctx->wf_P < P) {
+                    HIP_TRY(ctx, hipStreamSynchronize(st));
+                    (void)hipFree(ctx->wf_ray); (void)hipFree(ctx->wf_pixsmp); (void)hipFree(ctx->wf_depth); (void)hipFree(ctx->wf_hit_t); (void)hipFree(ctx->wf_hit_idx);
+                    (void)hipFree(ctx->wf_stacks); (void)hipFree(ctx->wf_q[0]); (void)hipFree(ctx->wf_q[1]); (void)hipFree(ctx->wf_n);
+                    ctx->wf_ray = nullptr; ctx->wf_pixsmp = nullptr; ctx->wf_depth = nullptr; ctx->wf_hit_t = nullptr; ctx->wf_hit_idx = nullptr;
+                    ctx->wf_stacks = nullptr; ctx->wf_q[0] = ctx->wf_q[1] = nullptr; ctx->wf_n = nullptr; ctx->wf_P = 0;
+                    HIP_TRY(ctx, hipMalloc(&ctx->wf_ray, (size_t)P * 6 * sizeof(float)));
+                    HIP_TRY(ctx, hipMalloc(&ctx->wf_pixsmp, (size_t)P * 3 * sizeof(uint32_t)));
+                    HIP_TRY(ctx, hipMalloc(&ctx->wf_depth, (size_t)P * sizeof(int)));
+                    HIP_TRY(ctx, hipMalloc(&ctx->wf_hit_t, (size_t)P * sizeof(float)));
+                    HIP_TRY(ctx, hipMalloc(&ctx->wf_hit_idx, (size_t)P * sizeof(int)));
+                    HIP_TRY(ctx, hipMalloc(&ctx->wf_stacks, (size_t)P * RT_MAX_DEPTH * sizeof(uint16_t)));
+                    HIP_TRY(ctx, hipMalloc(&ctx->wf_q[0], (size_t)P * sizeof(uint32_t)));
+                    HIP_TRY(ctx, hipMalloc(&ctx->wf_q[1], (size_t)P * sizeof(uint32_t)));
+                    HIP_TRY(ctx, hipMalloc(&ctx->wf_n, 2 * sizeof(uint32_t)));
+                    ctx->wf_P = P;
+                }
+                WfArgs w;
+                w.sw.frec = ctx->d_frec; w.sw.prec = ctx->d_prec; w.sw.plane_s0 = ctx->plane_s0; w.sw.geom = ctx->d_geom; w.sw.n = ctx->n; w.sw.n_pad = ctx->n_pad;
+                w.mat = ctx->d_mat; w.aux = ctx->d_aux; w.cam = ctx->cam;
+                w.ig.width = p->width; w.ig.height = p->height; w.ig.band_rows = p->band_rows; w.ig.band_first = p->band_first; w.ig.band_step = p->band_step;
+                w.ig.owned_rows = owned; w.ig.tiles_x = tiles_x; w.ig.Q = (uint32_t)Q; w.ig.s_begin = s0;
+                w.max_depth = p->max_depth; w.tmin = p->tmin; w.k0 = (uint32_t)p->seed; w.k1 = (uint32_t)(p->seed >> 32);
+                w.total_items = total; w.P = ctx->wf_P;
+                w.ray = ctx->wf_ray; w.pixsmp = ctx->wf_pixsmp; w.depth = ctx->wf_depth; w.hit_t = ctx->wf_hit_t; w.hit_idx = ctx->wf_hit_idx; w.stacks = ctx->wf_stacks;
+                w.work_counter = ctx->d_work; w.ray_counter = ctx->d_rays; w.samples = ctx->d_samples;
+                const bool wl = ctx->n <= 4096, wp = ctx->plane_filter;      // intersect keeps only the 16-byte exact records in LDS
+                const size_t wshmem = (wl ? (size_t)ctx->n * sizeof(float4) : 0) + (size_t)(kTraceBlock / 64) * kSuperChunkWords * 64 * sizeof(uint32_t);
+                int& wbpc = ctx->wf_blocks_per_cu[(wl ? 1 : 0) + (wp ? 2 : 0)];
+                auto ikern = wl ? (wp ? k_wf_intersect<true, true> : k_wf_intersect<true, false>) : (wp ? k_wf_intersect<false, true> : k_wf_intersect<false, false>);
+                if (wbpc == 0) { int nb = 0; if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, ikern, kTraceBlock, wshmem) != hipSuccess || nb <= 0) nb = 1; wbpc = nb; }
+                const unsigned igrid_cap = (unsigned)(ctx->num_cu * wbpc);
+                // queue 0 is filled by k_wf_init; then intersect/shade alternate between the two queues
+                w.q_in = ctx->wf_q[1]; w.q_out = ctx->wf_q[0]; w.n_in = ctx->wf_n + 1; w.n_out = ctx->wf_n + 0;
+                const uint32_t first = P < total ? P : total;
+                hipLaunchKernelGGL(k_wf_init, dim3((first + 255) / 256), dim3(256), 0, st, w);
+                HIP_TRY(ctx, hipGetLastError());
+                int cur = 0;
+                uint32_t live_upper = first;          // the queue never grows: slots are reused, not added
+                for (int iter = 0;; ++iter) {
+                    w.q_in = ctx->wf_q[cur]; w.q_out = ctx->wf_q[cur ^ 1]; w.n_in = ctx->wf_n + cur; w.n_out = ctx->wf_n + (cur ^ 1);
+                    HIP_TRY(ctx, hipMemsetAsync(ctx->wf_n + (cur ^ 1), 0, sizeof(uint32_t), st));
+                    unsigned ib = (live_upper + kTraceBlock - 1) / kTraceBlock; if (ib > igrid_cap) ib = igrid_cap; if (ib == 0) ib = 1;
+                    hipLaunchKernelGGL(ikern, dim3(ib), dim3(kTraceBlock), wshmem, st, w);
+                    hipLaunchKernelGGL(k_wf_shade, dim3((live_upper + 255) / 256), dim3(256), 0, st, w);
+                    HIP_TRY(ctx, hipGetLastError());
+                    cur ^= 1;
+                    if ((iter & 7) == 7) {              // the host steers the loop: read the live count every 8 bounces
+                        uint32_t live = 0;
+                        HIP_TRY(ctx, hipMemcpyAsync(&live, ctx->wf_n + cur, sizeof live, hipMemcpyDeviceToHost, st));
+                        HIP_TRY(ctx, hipStreamSynchronize(st));
+                        if (live == 0) break;
+                        live_upper = live;
+                    }
+                }
+                ResolveArgs r;
+                r.samples = ctx->d_samples; r.accum = ctx->d_accum; r.Q = (uint32_t)Q; r.tiles_x = tiles_x; r.s_count = sc;
+                r.first = (bi == 0); r.last = (bi == batches - 1); r.width = p->width; r.owned_rows = owned; r.spp = p->spp;
+                r.rgb_mean = d_rgb_mean; r.irgb = d_irgb;
+                hipLaunchKernelGGL(k_resolve, dim3((unsigned)((Q + 255) / 256)), dim3(256), 0, st, r);
+                HIP_TRY(ctx, hipGetLastError());
+                continue;
+            }
             TraceArgs a;
             a.prec = ctx->d_prec; a.plane_s0 = ctx->plane_s0; a.frec = ctx->d_frec; a.geom = ctx->d_geom; a.mat = ctx->d_mat; a.aux = ctx->d_aux; a.n = ctx->n; a.n_pad = ctx->n_pad; a.cam = ctx->cam;
             a.width = p->width; a.height = p->height; a.max_depth = p->max_depth; a.tmin = p->tmin;

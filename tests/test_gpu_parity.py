@@ -132,7 +132,7 @@ def _setup(rt, m):
         rt.set_camera(R.three_camera(m["nx"], m["ny"]))
 
 
-@pytest.mark.parametrize("mode", [R.MODE_MEGAKERNEL, R.MODE_PIXEL])
+@pytest.mark.parametrize("mode", [R.MODE_MEGAKERNEL, R.MODE_WAVEFRONT, R.MODE_PIXEL])
 @pytest.mark.parametrize("name", ["philox_final_96x64x4", "philox_final_40x30x16_ap0",
                                   "philox_three_hollow_80x45x8", "philox_three_64x36x32"])
 def test_render_is_bit_identical_to_reference_image(rt, name, mode):
@@ -224,6 +224,9 @@ def test_full_size_properties(rt):
     np.testing.assert_allclose(a.reshape(-1, 3).mean(0), [0.2995, 0.3498, 0.4462], atol=0.004)
     c, _, _, _ = rt.render(rt.params(1200, 800, 10, seed=1))
     assert not np.array_equal(a, c)
+    # the wavefront organisation of the same loop: same image, same ray count
+    w, iw, rays_w, _ = rt.render(rt.params(1200, 800, 10, seed=0, mode=R.MODE_WAVEFRONT))
+    assert rays_w == rays_a and np.array_equal(w.view(np.uint32), a.view(np.uint32)) and np.array_equal(iw, ia)
 
 
 def test_stress_scene_rows_match_oracle(rt):
@@ -247,8 +250,8 @@ def test_stress_scene_rows_match_oracle(rt):
     rgb, irgb, rays, _ = rt.render(rt.params(96, 64, 2, seed=8))
     want, wq, wrays = O.render(O.SceneArrays.from_table(table), O.final_camera(96, 64), 96, 64, 2, O.usrc_philox(8))
     assert rays == wrays and same(rgb, want) and np.array_equal(irgb, wq)
-    both = [rt.render(rt.params(96, 64, 2, seed=8, mode=m))[0] for m in (R.MODE_MEGAKERNEL, R.MODE_PIXEL)]
-    assert same(both[0], both[1])
+    both = [rt.render(rt.params(96, 64, 2, seed=8, mode=m))[0] for m in (R.MODE_MEGAKERNEL, R.MODE_PIXEL, R.MODE_WAVEFRONT)]
+    assert same(both[0], both[1]) and same(both[0], both[2])
 
 
 def test_filter_variants_agree(rt, monkeypatch):
