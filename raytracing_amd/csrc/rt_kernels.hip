@@ -166,8 +166,8 @@ __global__ void __launch_bounds__(kBlock) k_render_mega(const RenderArgs a)
 }
 
 // ============================================================================ persistent megakernel
-// Work item = one sample of one pixel.  Items are numbered sample-major over 8x8 pixel tiles,
-//   item = s_rel * Q + q,   q = tile * 64 + (row_in_tile * 8 + col_in_tile),
+// Work item = one sample of one pixel.  Items are numbered tile by tile over 8x8 pixel tiles,
+//   item = (tile * s_count + s_rel) * 64 + (row_in_tile * 8 + col_in_tile),
 // so the 64 items a fresh wave picks up are one tile at one sample (coherent primary rays) and
 // both this kernel's stores and the resolve kernel's loads of the sample buffer are coalesced.
 // A wave draws items from a chunk it reserves with one atomic on a global counter; whenever a
@@ -424,14 +424,15 @@ __device__ __forceinline__ bool shade_step(RayD& ray, int& depth, float closest,
     return done;
 }
 
-// Work item -> (pixel key, sample, pixel coordinates).  Items are numbered sample-major over 8x8 tiles:
-// item = s_rel * Q + q, q = tile * 64 + row_in_tile * 8 + col_in_tile.  Returns false for the padding
-// pixels of edge tiles.
-struct ItemGeometry { int width, height, band_rows, band_first, band_step, owned_rows, tiles_x; uint32_t Q; int s_begin; };
+// Work item -> (pixel key, sample, pixel coordinates).  Items are numbered tile by tile, then sample by
+// sample, then pixel by pixel inside the 8x8 tile: item = (tile * s_count + s_rel) * 64 + row_in_tile * 8 +
+// col_in_tile, so 512 consecutive items are eight samples of ONE tile.  Returns false for the padding pixels
+// of edge tiles.
+struct ItemGeometry { int width, height, band_rows, band_first, band_step, owned_rows, tiles_x; uint32_t Q; int s_begin, s_count; };
 __device__ __forceinline__ bool decode_item(const ItemGeometry& ig, uint32_t item, uint32_t& pix, uint32_t& smp, int& i, int& j)
 {
-    const uint32_t s_rel = item / ig.Q, q = item - s_rel * ig.Q;
-    const uint32_t tile = q >> 6, l = q & 63u;
+    const uint32_t ts = item >> 6, l = item & 63u;
+    const uint32_t tile = ts / (uint32_t)ig.s_count, s_rel = ts - tile * (uint32_t)ig.s_count;
     const int ty = (int)(tile / (uint32_t)ig.tiles_x), tx = (int)(tile - (uint32_t)ty * (uint32_t)ig.tiles_x);
     i = tx * 8 + (int)(l & 7u);
     const int r = ty * 8 + (int)(l >> 3);
@@ -481,7 +482,7 @@ __global__ void __launch_bounds__(kTraceBlock) k_trace(const TraceArgs a)
     const float fnx = (float)a.width, fny = (float)a.height;
     SecTimer T; T.start();
     ItemGeometry ig; ig.width = a.width; ig.height = a.height; ig.band_rows = a.band_rows; ig.band_first = a.band_first; ig.band_step = a.band_step;
-    ig.owned_rows = a.owned_rows; ig.tiles_x = a.tiles_x; ig.Q = a.Q; ig.s_begin = a.s_begin;
+    ig.owned_rows = a.owned_rows; ig.tiles_x = a.tiles_x; ig.Q = a.Q; ig.s_begin = a.s_begin; ig.s_count = a.s_count;
     SweepScene sw; sw.frec = a.frec; sw.prec = a.prec; sw.plane_s0 = a.plane_s0; sw.geom = a.geom; sw.n = a.n; sw.n_pad = a.n_pad;
 
     for (;;) {
@@ -580,8 +581,8 @@ __global__ void __launch_bounds__(256) k_resolve(const ResolveArgs a)
     const int ty = (int)(tile / (uint32_t)a.tiles_x), tx = (int)(tile - (uint32_t)ty * (uint32_t)a.tiles_x);
     const int i = tx * 8 + (int)(l & 7u), r = ty * 8 + (int)(l >> 3);
     if (i >= a.width || r >= a.owned_rows) return;
-    const float* sp = a.samples + 3 * (size_t)q;
-    for (int s = 0; s < a.s_count; ++s, sp += 3 * (size_t)a.Q) col = col + mk(sp[0], sp[1], sp[2]);
+    const float* sp = a.samples + 3 * ((size_t)tile * a.s_count * 64 + l);       // item = (tile * s_count + s) * 64 + l
+    for (int s = 0; s < a.s_count; ++s, sp += 3 * 64) col = col + mk(sp[0], sp[1], sp[2]);
     if (!a.last) { a.accum[3 * (size_t)q] = col.x; a.accum[3 * (size_t)q + 1] = col.y; a.accum[3 * (size_t)q + 2] = col.z; return; }
     const float inv = 1.0f / (float)a.spp;          // Vec3::operator/=(float), vec3.cpp:109-118
     const float mr = col.x * inv, mg = col.y * inv, mb = col.z * inv;
@@ -1069,7 +1070,7 @@ int rt_render_device(rt_context* ctx, const rt_params* p, float* d_rgb_mean, int
                 w.sw.frec = ctx->d_frec; w.sw.prec = ctx->d_prec; w.sw.plane_s0 = ctx->plane_s0; w.sw.geom = ctx->d_geom; w.sw.n = ctx->n; w.sw.n_pad = ctx->n_pad;
                 w.mat = ctx->d_mat; w.aux = ctx->d_aux; w.cam = ctx->cam;
                 w.ig.width = p->width; w.ig.height = p->height; w.ig.band_rows = p->band_rows; w.ig.band_first = p->band_first; w.ig.band_step = p->band_step;
-                w.ig.owned_rows = owned; w.ig.tiles_x = tiles_x; w.ig.Q = (uint32_t)Q; w.ig.s_begin = s0;
+                w.ig.owned_rows = owned; w.ig.tiles_x = tiles_x; w.ig.Q = (uint32_t)Q; w.ig.s_begin = s0; w.ig.s_count = sc;
                 w.max_depth = p->max_depth; w.tmin = p->tmin; w.k0 = (uint32_t)p->seed; w.k1 = (uint32_t)(p->seed >> 32);
                 w.total_items = total; w.P = ctx->wf_P;
                 w.ray = ctx->wf_ray; w.pixsmp = ctx->wf_pixsmp; w.depth = ctx->wf_depth; w.hit_t = ctx->wf_hit_t; w.hit_idx = ctx->wf_hit_idx; w.stacks = ctx->wf_stacks;
