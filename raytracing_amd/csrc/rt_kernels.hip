@@ -183,8 +183,8 @@ __global__ void __launch_bounds__(kBlock) k_render_mega(const RenderArgs a)
 //            unfused arithmetic (sphere.cpp:15-52) in ascending index order with the shrinking
 //            upper bound of hittablelist.cpp:13-31, so the chosen sphere and t are bit-identical.
 struct TraceArgs {
-    const float4* prec;      // plane-filter records (cx, cz, -(r^2 + slack_i), 0), same padding as frec
-    float plane_s0;          // constant part of the plane filter's per-ray slack
+    const float4* prec;      // plane-filter records (cx, cz, R_i = r^2 + slack_i, 0), same padding as frec
+    float plane_s0, plane_rmin;   // plane filter: constant part of the per-ray slack, smallest R_i
     const float4* frec;      // filter records (cx, cy, cz, |c|^2 - r^2 - slack), padded to a multiple of 32
     const float4* geom; const float4* mat; const Aux* aux; int n, n_pad;
     CameraD cam;
@@ -232,8 +232,9 @@ static constexpr float kPlaneRaySlack = 128.0f * 5.9604645e-08f;
 // the wavefront intersect kernel.  mask_words: this lane's column of kSuperChunkWords LDS words.
 struct SweepScene {
     const float4* frec;      // disc-filter records (cx, cy, cz, |c|^2 - r^2 - slack), padded to a multiple of 8
-    const float4* prec;      // plane-filter records (cx, cz, -(r^2 + slack_i), 0), same padding
+    const float4* prec;      // plane-filter records (cx, cz, R_i = r^2 + slack_i, 0), same padding
     float plane_s0;          // constant part of the plane filter's per-ray slack
+    float plane_rmin;        // smallest R_i over the non-degenerate spheres
     const float4* geom;      // exact records in HBM (used when they are not mirrored in LDS)
     int n, n_pad;
 };
@@ -242,148 +243,154 @@ template <bool kLds, bool kPlane, bool kRecLds>
 __device__ __forceinline__ void closest_hit(const RayD& ray, float tmin, const SweepScene& sw, const float4* s_geom, const float4* s_prec,
                                             uint32_t* mask_words, float& closest, int& hit, SecTimer& T)
 {
-                            // Per ray: unit direction (approximate is enough for a conservative test), -(o.d^), 2o,
-                // -|o|^2 (1 - slack).  Per sphere record (cx, cy, cz, k), k = |c|^2 - r^2 - slack_i:
-                //   b = c.d^ - o.d^            3 FMA      w = 2 o.c - |o|^2'        3 FMA
-                //   e = b*b + w                1 FMA      s = e - k                 1 SUB   -> sign bit
-                // s >= 0 is necessary for the reference's discriminant to be positive.
-                const float qa = dot(ray.d, ray.d);
-                const float rs = __frsqrt_rn(fmaf(ray.d.x, ray.d.x, fmaf(ray.d.y, ray.d.y, ray.d.z * ray.d.z)));
-                const float hx = ray.d.x * rs, hy = ray.d.y * rs, hz = ray.d.z * rs;
-                const float nod = -fmaf(ray.o.x, hx, fmaf(ray.o.y, hy, ray.o.z * hz));
-                const float p2x = 2.0f * ray.o.x, p2y = 2.0f * ray.o.y, p2z = 2.0f * ray.o.z;
-                const float oo = fmaf(ray.o.x, ray.o.x, fmaf(ray.o.y, ray.o.y, ray.o.z * ray.o.z));
-                const float noo = kRaySlack * oo - oo;
-                // Plane filter (kPlane): the vertical plane through the ray has a horizontal normal u perp d, so
-                // the signed distance of a centre to it is pu = cx*ux + cz*uz - o.u (2 FMA).  The reference
-                // accepts a sphere only if its discriminant b^2 - a c is positive, and in its float arithmetic
-                // that can happen for a line passing up to sqrt(r^2 + 32 ulp (|o-c|^2 + r^2)) from the centre,
-                // so the test is pu^2 - R_i <= S_ray with that allowance (and this form's own rounding) split
-                // into a per-sphere part R_i (host) and a per-ray part S_ray: 3 FMA + 1 SUB per pair.
-                float ux = 1.0f, uz = 0.0f, nou = 0.0f, s_ray = 0.0f;
-                if (kPlane) {
-                    const float h2 = fmaf(hx, hx, hz * hz);
-                    if (h2 > 1e-12f) { const float ih = __frsqrt_rn(h2); ux = hz * ih; uz = -hx * ih; }
-                    nou = -fmaf(ray.o.x, ux, ray.o.z * uz);
-                    s_ray = fmaf(kPlaneRaySlack, oo, sw.plane_s0);
-                }
-                            // Filter records are read through the constant address space: the index is wave-uniform,
-                // so each record arrives by scalar load in SGPRs and feeds the FMAs as a scalar operand.
-                typedef float f4v __attribute__((ext_vector_type(4)));
-                typedef const __attribute__((address_space(4))) f4v* ConstRec;
-                const ConstRec frec_k = (ConstRec)(sw.frec);
-                const ConstRec prec_k = (ConstRec)(sw.prec);
+    // Per ray: unit direction (approximate is enough for a conservative test), -(o.d^), 2o,
+    // -|o|^2 (1 - slack).  Per sphere record (cx, cy, cz, k), k = |c|^2 - r^2 - slack_i:
+    //   b = c.d^ - o.d^            3 FMA      w = 2 o.c - |o|^2'        3 FMA
+    //   e = b*b + w                1 FMA      s = e - k                 1 SUB   -> sign bit
+    // s >= 0 is necessary for the reference's discriminant to be positive.
+    const float qa = dot(ray.d, ray.d);
+    const float rs = __frsqrt_rn(fmaf(ray.d.x, ray.d.x, fmaf(ray.d.y, ray.d.y, ray.d.z * ray.d.z)));
+    const float hx = ray.d.x * rs, hy = ray.d.y * rs, hz = ray.d.z * rs;
+    const float nod = -fmaf(ray.o.x, hx, fmaf(ray.o.y, hy, ray.o.z * hz));
+    const float p2x = 2.0f * ray.o.x, p2y = 2.0f * ray.o.y, p2z = 2.0f * ray.o.z;
+    const float oo = fmaf(ray.o.x, ray.o.x, fmaf(ray.o.y, ray.o.y, ray.o.z * ray.o.z));
+    const float noo = kRaySlack * oo - oo;
+    // Plane filter (kPlane): the vertical plane through the ray has a horizontal normal u perp d, so
+    // the signed distance of a centre to it is pu = cx*ux + cz*uz - o.u (2 FMA).  The reference
+    // accepts a sphere only if its discriminant b^2 - a c is positive, and in its float arithmetic
+    // that can happen for a line passing up to sqrt(r^2 + 32 ulp (|o-c|^2 + r^2)) from the centre,
+    // so the test is pu^2 <= R_i + S_ray with that allowance (and this form's own rounding) split
+    // into a per-sphere part R_i (host) and a per-ray part S_ray.
+    float ux = 1.0f, uz = 0.0f, nou = 0.0f, s_ray = 0.0f;
+    if (kPlane) {
+        const float h2 = fmaf(hx, hx, hz * hz);
+        if (h2 > 1e-12f) { const float ih = __frsqrt_rn(h2); ux = hz * ih; uz = -hx * ih; }
+        // Fold the per-ray allowance S_ray into the normal instead of subtracting it per pair: with
+        // kappa^2 = Rmin / (Rmin + S_ray), (kappa pu)^2 <= R_i holds whenever pu^2 <= R_i + S_ray and
+        // R_i >= Rmin, so the per-pair test is the sign of R_i - pu'^2 alone (3 FMA per pair).
+        s_ray = fmaf(kPlaneRaySlack, oo, sw.plane_s0);
+        const float k2 = sw.plane_rmin / (sw.plane_rmin + s_ray);
+        const float kappa = sqrtf(k2) * (1.0f - 4.0f * 5.9604645e-08f);
+        ux *= kappa; uz *= kappa;
+        nou = -fmaf(ray.o.x, ux, ray.o.z * uz);
+    }
+    // Filter records are read through the constant address space: the index is wave-uniform,
+    // so each record arrives by scalar load in SGPRs and feeds the FMAs as a scalar operand.
+    typedef float f4v __attribute__((ext_vector_type(4)));
+    typedef const __attribute__((address_space(4))) f4v* ConstRec;
+    const ConstRec frec_k = (ConstRec)(sw.frec);
+    const ConstRec prec_k = (ConstRec)(sw.prec);
 
-                // Filter one 32-sphere chunk (or a shorter tail, a multiple of 8): kCount sign bits, left-aligned
-                // (bit 31 = first record of the chunk), 1 = rejected.
-                auto filter_bits = [&](int base, auto count_tag) -> uint32_t {
-                    constexpr int kCount = decltype(count_tag)::value;
-                    uint32_t mask = 0u;
-    #pragma unroll
-                    for (int jj = 0; jj < kCount; ++jj) {
-                        float sgn;
-                        if (kPlane) {
-                            float fx, fy, fz;
-                            if (kRecLds) { const float4 f = s_prec[base + jj]; fx = f.x; fy = f.y; fz = f.z; }
-                            else { const f4v f = prec_k[base + jj]; fx = f.x; fy = f.y; fz = f.z; }
-                            const float pu = fmaf(fx, ux, fmaf(fy, uz, nou));
-                            sgn = s_ray - fmaf(pu, pu, fz);
-                        } else {
-                            const f4v f = frec_k[base + jj];
-                            const float b = fmaf(f.x, hx, fmaf(f.y, hy, fmaf(f.z, hz, nod)));
-                            const float w = fmaf(f.x, p2x, fmaf(f.y, p2y, fmaf(f.z, p2z, noo)));
-                            const float e = fmaf(b, b, w);
-                            sgn = e - f.w;
-                        }
-                        mask = __builtin_amdgcn_alignbit(mask, __float_as_uint(sgn), 31);   // append sign bit
-                    }
-                    return mask;
-                };
+    // Filter one 32-sphere chunk (or a shorter tail, a multiple of 8): kCount sign bits, left-aligned
+    // (bit 31 = first record of the chunk), 1 = rejected.
+    auto filter_bits = [&](int base, auto count_tag) -> uint32_t {
+        constexpr int kCount = decltype(count_tag)::value;
+        uint32_t mask = 0u;
+#pragma unroll
+        for (int jj = 0; jj < kCount; ++jj) {
+            float sgn;
+            if (kPlane) {
+                float fx, fy, fz;
+                if (kRecLds) { const float4 f = s_prec[base + jj]; fx = f.x; fy = f.y; fz = f.z; }
+                else { const f4v f = prec_k[base + jj]; fx = f.x; fy = f.y; fz = f.z; }
+                const float pu = fmaf(fx, ux, fmaf(fy, uz, nou));
+                sgn = fmaf(-pu, pu, fz);
+            } else {
+                const f4v f = frec_k[base + jj];
+                const float b = fmaf(f.x, hx, fmaf(f.y, hy, fmaf(f.z, hz, nod)));
+                const float w = fmaf(f.x, p2x, fmaf(f.y, p2y, fmaf(f.z, p2z, noo)));
+                const float e = fmaf(b, b, w);
+                sgn = e - f.w;
+            }
+            mask = __builtin_amdgcn_alignbit(mask, __float_as_uint(sgn), 31);   // append sign bit
+        }
+        return mask;
+    };
 
-                T.mark(1);
-                // Super-chunks of up to 16 mask words (512 spheres).  The filter only stores each word and notes
-                // whether it has a survivor; afterwards one loop per lane walks its surviving bits in ascending
-                // sphere order and runs the exact test of sphere.cpp:15-52 with the shrinking upper bound of
-                // hittablelist.cpp:21-29 (unfused arithmetic).
-                for (int sbase = 0; sbase < sw.n_pad; sbase += 32 * kSuperChunkWords) {
-                    uint32_t nz = 0u;          // bit (31 - w) set: word w of this super-chunk has a survivor
-                    int words = 0;
-                    int base = sbase;
-                    const int send = (sw.n_pad - sbase < 32 * kSuperChunkWords) ? sw.n_pad : sbase + 32 * kSuperChunkWords;
-                    for (; base + 32 <= send; base += 32, ++words) {
-                        const uint32_t cand = ~filter_bits(base, std::integral_constant<int, 32>());
-                        mask_words[words * 64] = cand;
-                        nz = __builtin_amdgcn_alignbit(nz, cand | (0u - cand), 31);
-                    }
-                    if (base < send) {         // tail: 8, 16 or 24 records
-                        uint32_t m = 0u; int got = 0;
-                        for (; base < send; base += 8, got += 8) m = (m << 8) | filter_bits(base, std::integral_constant<int, 8>());
-                        const uint32_t cand = (~m) << (32 - got);
-                        mask_words[words * 64] = cand;
-                        nz = __builtin_amdgcn_alignbit(nz, cand | (0u - cand), 31);
-                        ++words;
-                    }
-                    nz <<= (32 - words);
-                    T.mark(1);
-                    // Pass A: exact discriminant of every survivor of the filter (sphere.cpp:17-25); the bits of
-                    // those with desc <= 0 are cleared in place.  Pass B: roots, range test and running minimum
-                    // (sphere.cpp:27-50, hittablelist.cpp:21-29) for what is left, in ascending index order.
-                    // Splitting keeps the square root and the two divisions out of the long first loop, where
-                    // some lane of the wave would otherwise need them on every trip.
-                    uint32_t nzb = 0u;
-                    {
-                        uint32_t cand = 0u, keep = 0u; int cbase = 0, w = -1;
-                        for (;;) {
-                            if (cand == 0u) {
-                                if (w >= 0) { mask_words[w * 64] = keep; if (keep) nzb |= 0x80000000u >> w; }
-                                if (nz == 0u) break;
-                                w = __clz((int)nz);
-                                nz &= ~(0x80000000u >> w);
-                                cand = mask_words[w * 64];
-                                keep = 0u;
-                                cbase = sbase + (w << 5);
-                            }
-                            const int jj = __clz((int)cand);
-                            const uint32_t bit = 0x80000000u >> jj;
-                            cand &= ~bit;
-                            const int k = cbase + jj;
-                            if (k < sw.n) {
-                                const float4 g = kLds ? s_geom[k] : sw.geom[k];
-                                const V3 oc = ray.o - mk(g.x, g.y, g.z);
-                                const float b = dot(oc, ray.d);
-                                const float cc = dot(oc, oc) - g.w;
-                                const float desc = b * b - qa * cc;
-                                if (desc > 0.0f) keep |= bit;
-                            }
-                        }
-                    }
-                    T.mark(2);
-                    {
-                        uint32_t cand = 0u; int cbase = 0;
-                        for (;;) {
-                            if (cand == 0u) {
-                                if (nzb == 0u) break;
-                                const int w = __clz((int)nzb);
-                                nzb &= ~(0x80000000u >> w);
-                                cand = mask_words[w * 64];
-                                cbase = sbase + (w << 5);
-                            }
-                            const int jj = __clz((int)cand);
-                            cand &= ~(0x80000000u >> jj);
-                            const int k = cbase + jj;
-                            const float4 g = kLds ? s_geom[k] : sw.geom[k];
-                            const V3 oc = ray.o - mk(g.x, g.y, g.z);
-                            const float b = dot(oc, ray.d);
-                            const float cc = dot(oc, oc) - g.w;
-                            const float desc = b * b - qa * cc;
-                            const float sq = sqrtf(desc);
-                            float temp = (-b - sq) / qa;
-                            if (!(temp < closest && temp > tmin)) temp = (-b + sq) / qa;
-                            if (temp < closest && temp > tmin) { closest = temp; hit = k; }
-                        }
-                    }
-                    T.mark(3);
+    T.mark(1);
+    // Super-chunks of up to 16 mask words (512 spheres).  The filter only stores each word and notes
+    // whether it has a survivor; afterwards one loop per lane walks its surviving bits in ascending
+    // sphere order and runs the exact test of sphere.cpp:15-52 with the shrinking upper bound of
+    // hittablelist.cpp:21-29 (unfused arithmetic).
+    for (int sbase = 0; sbase < sw.n_pad; sbase += 32 * kSuperChunkWords) {
+        uint32_t nz = 0u;          // bit (31 - w) set: word w of this super-chunk has a survivor
+        int words = 0;
+        int base = sbase;
+        const int send = (sw.n_pad - sbase < 32 * kSuperChunkWords) ? sw.n_pad : sbase + 32 * kSuperChunkWords;
+        for (; base + 32 <= send; base += 32, ++words) {
+            const uint32_t cand = ~filter_bits(base, std::integral_constant<int, 32>());
+            mask_words[words * 64] = cand;
+            nz = __builtin_amdgcn_alignbit(nz, cand | (0u - cand), 31);
+        }
+        if (base < send) {         // tail: 8, 16 or 24 records
+            uint32_t m = 0u; int got = 0;
+            for (; base < send; base += 8, got += 8) m = (m << 8) | filter_bits(base, std::integral_constant<int, 8>());
+            const uint32_t cand = (~m) << (32 - got);
+            mask_words[words * 64] = cand;
+            nz = __builtin_amdgcn_alignbit(nz, cand | (0u - cand), 31);
+            ++words;
+        }
+        nz <<= (32 - words);
+        T.mark(1);
+        // Pass A: exact discriminant of every survivor of the filter (sphere.cpp:17-25); the bits of
+        // those with desc <= 0 are cleared in place.  Pass B: roots, range test and running minimum
+        // (sphere.cpp:27-50, hittablelist.cpp:21-29) for what is left, in ascending index order.
+        // Splitting keeps the square root and the two divisions out of the long first loop, where
+        // some lane of the wave would otherwise need them on every trip.
+        uint32_t nzb = 0u;
+        {
+            uint32_t cand = 0u, keep = 0u; int cbase = 0, w = -1;
+            for (;;) {
+                if (cand == 0u) {
+                    if (w >= 0) { mask_words[w * 64] = keep; if (keep) nzb |= 0x80000000u >> w; }
+                    if (nz == 0u) break;
+                    w = __clz((int)nz);
+                    nz &= ~(0x80000000u >> w);
+                    cand = mask_words[w * 64];
+                    keep = 0u;
+                    cbase = sbase + (w << 5);
                 }
+                const int jj = __clz((int)cand);
+                const uint32_t bit = 0x80000000u >> jj;
+                cand &= ~bit;
+                const int k = cbase + jj;
+                if (k < sw.n) {
+                    const float4 g = kLds ? s_geom[k] : sw.geom[k];
+                    const V3 oc = ray.o - mk(g.x, g.y, g.z);
+                    const float b = dot(oc, ray.d);
+                    const float cc = dot(oc, oc) - g.w;
+                    const float desc = b * b - qa * cc;
+                    if (desc > 0.0f) keep |= bit;
+                }
+            }
+        }
+        T.mark(2);
+        {
+            uint32_t cand = 0u; int cbase = 0;
+            for (;;) {
+                if (cand == 0u) {
+                    if (nzb == 0u) break;
+                    const int w = __clz((int)nzb);
+                    nzb &= ~(0x80000000u >> w);
+                    cand = mask_words[w * 64];
+                    cbase = sbase + (w << 5);
+                }
+                const int jj = __clz((int)cand);
+                cand &= ~(0x80000000u >> jj);
+                const int k = cbase + jj;
+                const float4 g = kLds ? s_geom[k] : sw.geom[k];
+                const V3 oc = ray.o - mk(g.x, g.y, g.z);
+                const float b = dot(oc, ray.d);
+                const float cc = dot(oc, oc) - g.w;
+                const float desc = b * b - qa * cc;
+                const float sq = sqrtf(desc);
+                float temp = (-b - sq) / qa;
+                if (!(temp < closest && temp > tmin)) temp = (-b + sq) / qa;
+                if (temp < closest && temp > tmin) { closest = temp; hit = k; }
+            }
+        }
+        T.mark(3);
+    }
 }
 
 // ============================================================================ shading step of Color()
@@ -483,7 +490,7 @@ __global__ void __launch_bounds__(kTraceBlock) k_trace(const TraceArgs a)
     SecTimer T; T.start();
     ItemGeometry ig; ig.width = a.width; ig.height = a.height; ig.band_rows = a.band_rows; ig.band_first = a.band_first; ig.band_step = a.band_step;
     ig.owned_rows = a.owned_rows; ig.tiles_x = a.tiles_x; ig.Q = a.Q; ig.s_begin = a.s_begin; ig.s_count = a.s_count;
-    SweepScene sw; sw.frec = a.frec; sw.prec = a.prec; sw.plane_s0 = a.plane_s0; sw.geom = a.geom; sw.n = a.n; sw.n_pad = a.n_pad;
+    SweepScene sw; sw.frec = a.frec; sw.prec = a.prec; sw.plane_s0 = a.plane_s0; sw.plane_rmin = a.plane_rmin; sw.geom = a.geom; sw.n = a.n; sw.n_pad = a.n_pad;
 
     for (;;) {
         // ---------------------------------------------------------------- hand out new items
@@ -778,7 +785,7 @@ struct rt_context {
     int device = -1;
     std::string error;
     float4* d_geom = nullptr; float4* d_mat = nullptr; Aux* d_aux = nullptr; int n = 0;
-    float4* d_frec = nullptr; float4* d_prec = nullptr; float plane_s0 = 0.0f; int n_pad = 0;
+    float4* d_frec = nullptr; float4* d_prec = nullptr; float plane_s0 = 0.0f; float plane_rmin = 1.0f; int n_pad = 0;
     bool plane_filter = true;
     bool records_in_lds = false;      // measurement variant, RT_AMD_RECORDS=lds
     float* d_samples = nullptr; size_t samples_bytes = 0;      // sample buffer of the persistent megakernel
@@ -919,19 +926,23 @@ int rt_upload_scene(rt_context* ctx, int n, const float* cx, const float* cy, co
         if ((double)kf > k) kf = nextafterf(kf, -INFINITY);
         frec[i] = make_float4(cx[i], cy[i], cz[i], kf);
     }
-    // Plane-filter records (cx, cz, -(r^2 + slack_i), 0).  u = 2^-24.  Allowance for the reference's own
+    // Plane-filter records (cx, cz, R_i = r^2 + slack_i, 0).  u = 2^-24.  Allowance for the reference's own
     // discriminant rounding: 32 u (|o-c|^2 + r^2) <= 64 u (|o|^2 + |c|^2) + 32 u r^2; this form's rounding
     // of pu (< 8 u (|c| + |o|)) moves pu^2 near the threshold by < 16 u |r| (|c| + |o|)
     // <= 8 u (2 r^2 + |c|^2 + |o|^2).  slack_i = u (128 |c|^2 + 64 r^2), S_ray = 128 u |o|^2 (kernel).
-    std::vector<float4> prec(n_pad, make_float4(0.0f, 0.0f, FLT_MAX, 0.0f));
+    std::vector<float4> prec(n_pad, make_float4(0.0f, 0.0f, -FLT_MAX, 0.0f));
+    double rmin_R = 1e30;
     for (int i = 0; i < n; ++i) {
         const double rr = (double)radius[i] * radius[i];
         const double cc = (double)cx[i] * cx[i] + (double)cy[i] * cy[i] + (double)cz[i] * cz[i];
         const double R = rr + 5.9604644775390625e-08 * (128.0 * cc + 64.0 * rr) + 1e-30;
         float rf = (float)R; if ((double)rf < R) rf = nextafterf(rf, INFINITY);
-        prec[i] = make_float4(cx[i], cz[i], -rf, 0.0f);
+        prec[i] = make_float4(cx[i], cz[i], rr > 1e-12 ? rf : FLT_MAX, 0.0f);     // zero-radius spheres always go to the exact test
+        if (rr > 1e-12 && (double)rf < rmin_R) rmin_R = (double)rf;
     }
     const float plane_s0 = 1e-30f;
+    if (rmin_R > 1e29) rmin_R = 1.0;
+    const float plane_rmin = nextafterf((float)rmin_R, 0.0f);
     for (int i = 0; i < n; ++i) {
         if (material[i] < RT_LAMBERTIAN || material[i] > RT_DIELECTRIC) return fail(ctx, RT_ERR_INVALID, "rt_upload_scene: sphere %d has unknown material %d", i, material[i]);
         geom[i] = make_float4(cx[i], cy[i], cz[i], radius[i] * radius[i]);
@@ -945,7 +956,7 @@ int rt_upload_scene(rt_context* ctx, int n, const float* cx, const float* cy, co
     ctx->d_geom = nullptr; ctx->d_mat = nullptr; ctx->d_aux = nullptr; ctx->d_frec = nullptr; ctx->d_prec = nullptr; ctx->n = 0;
     HIP_TRY(ctx, hipMalloc(&ctx->d_prec, sizeof(float4) * n_pad));
     HIP_TRY(ctx, hipMemcpy(ctx->d_prec, prec.data(), sizeof(float4) * n_pad, hipMemcpyHostToDevice));
-    ctx->plane_s0 = plane_s0;
+    ctx->plane_s0 = plane_s0; ctx->plane_rmin = plane_rmin;
     HIP_TRY(ctx, hipMalloc(&ctx->d_frec, sizeof(float4) * n_pad));
     HIP_TRY(ctx, hipMemcpy(ctx->d_frec, frec.data(), sizeof(float4) * n_pad, hipMemcpyHostToDevice));
     ctx->n_pad = n_pad;
@@ -1067,7 +1078,7 @@ int rt_render_device(rt_context* ctx, const rt_params* p, float* d_rgb_mean, int
                     ctx->wf_P = P;
                 }
                 WfArgs w;
-                w.sw.frec = ctx->d_frec; w.sw.prec = ctx->d_prec; w.sw.plane_s0 = ctx->plane_s0; w.sw.geom = ctx->d_geom; w.sw.n = ctx->n; w.sw.n_pad = ctx->n_pad;
+                w.sw.frec = ctx->d_frec; w.sw.prec = ctx->d_prec; w.sw.plane_s0 = ctx->plane_s0; w.sw.plane_rmin = ctx->plane_rmin; w.sw.geom = ctx->d_geom; w.sw.n = ctx->n; w.sw.n_pad = ctx->n_pad;
                 w.mat = ctx->d_mat; w.aux = ctx->d_aux; w.cam = ctx->cam;
                 w.ig.width = p->width; w.ig.height = p->height; w.ig.band_rows = p->band_rows; w.ig.band_first = p->band_first; w.ig.band_step = p->band_step;
                 w.ig.owned_rows = owned; w.ig.tiles_x = tiles_x; w.ig.Q = (uint32_t)Q; w.ig.s_begin = s0; w.ig.s_count = sc;
@@ -1113,7 +1124,7 @@ int rt_render_device(rt_context* ctx, const rt_params* p, float* d_rgb_mean, int
                 continue;
             }
             TraceArgs a;
-            a.prec = ctx->d_prec; a.plane_s0 = ctx->plane_s0; a.frec = ctx->d_frec; a.geom = ctx->d_geom; a.mat = ctx->d_mat; a.aux = ctx->d_aux; a.n = ctx->n; a.n_pad = ctx->n_pad; a.cam = ctx->cam;
+            a.prec = ctx->d_prec; a.plane_s0 = ctx->plane_s0; a.plane_rmin = ctx->plane_rmin; a.frec = ctx->d_frec; a.geom = ctx->d_geom; a.mat = ctx->d_mat; a.aux = ctx->d_aux; a.n = ctx->n; a.n_pad = ctx->n_pad; a.cam = ctx->cam;
             a.width = p->width; a.height = p->height; a.max_depth = p->max_depth; a.tmin = p->tmin;
             a.k0 = (uint32_t)p->seed; a.k1 = (uint32_t)(p->seed >> 32);
             a.band_rows = p->band_rows; a.band_first = p->band_first; a.band_step = p->band_step; a.owned_rows = owned;
