@@ -28,6 +28,9 @@ from raytracing_amd import dist as rdist                     # noqa: E402
 PEAK_FP32_VALU_TFLOPS = 157.3      # 256 CU x 4 SIMD x 32 lanes x 2 flop (FMA) x 2.4 GHz
 FLOP_PER_TEST = 18                 # oc (3) + oc.d (5) + oc.oc (5) + -r^2 (1) + b^2 (1) + a*c (1) + - (1) + compare (1)
 FLOP_PER_RAY_EXTRA = 150           # hit resolve + scatter, per closest-hit query
+# HBM bytes per ray of the render kernels from rocprofv3 FETCH_SIZE (x2, the gfx950 correction for coalesced reads) + WRITE_SIZE
+# (profiles/r01_pmc_traffic.txt); a profiled constant, not measured inside this script
+HBM_BYTES_PER_RAY_PMC = 41.0
 
 WORKLOADS = {
     # name: (scene, width, height, spp)
@@ -75,7 +78,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--workload", default="c3", choices=sorted(WORKLOADS))
     ap.add_argument("--spp", type=int, default=0, help="override samples per pixel")
-    ap.add_argument("--band-rows", type=int, default=8)
+    ap.add_argument("--band-rows", type=int, default=0, help="rows per band (0 = largest of 8,4,2,1 that gives every rank the same number of bands)")
     ap.add_argument("--seed", type=int, default=0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--mode", default="megakernel", choices=["megakernel", "wavefront", "pixel"])
@@ -119,6 +122,8 @@ def main():
     n_spheres = len(table)
 
     band = args.band_rows
+    if band <= 0:
+        band = next((b for b in (8, 4, 2, 1) if height % b == 0 and (height // b) % world == 0), 8)
     mode = {"megakernel": R.MODE_MEGAKERNEL, "wavefront": R.MODE_WAVEFRONT, "pixel": R.MODE_PIXEL}[args.mode]
     p = rt.params(width, height, spp, seed=args.seed, band_rows=band, band_first=rank, band_step=world, mode=mode)
     pad = rdist.max_owned_rows(height, band, world)
@@ -182,7 +187,8 @@ def main():
             "msamples_per_s": samples / elapsed / 1e6, "rays_per_sample": total_rays / samples,
             "kernel_ms_mean": kms_mean, "kernel_ms_max": kms_max,
             "roofline": {"bound": "valu", "achieved": achieved, "peak": PEAK_FP32_VALU_TFLOPS, "unit": "TFLOP/s",
-                         "frac": achieved / PEAK_FP32_VALU_TFLOPS, "traffic": None,
+                         "frac": achieved / PEAK_FP32_VALU_TFLOPS,
+                         "traffic": (HBM_BYTES_PER_RAY_PMC * my_rays) if args.mode == "megakernel" else None, "traffic_unit": "bytes per step of this rank (PMC-derived constant per ray)",
                          "kernel": {"megakernel": "k_trace", "wavefront": "k_wf_intersect + k_wf_shade", "pixel": "k_render_mega"}[args.mode], "flop_per_ray": flop_per_ray,
                          "note": "FP32 vector-ALU bound (HBM traffic and MFMA are not on this path); algorithmic flops = rays x (18 x spheres + 150)"},
         }
