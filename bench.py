@@ -48,14 +48,10 @@ def cpu_baseline(width, height, spp):
     C port of the oracle when the reference build is not present."""
     rows = 40
     j0 = height // 2 - rows // 2
-    ref = os.path.join(ROOT, "oracle", "_ref", "libref_render.so")
-    if os.path.exists(ref):
-        L = C.CDLL(ref)
-        L.ref_render_rows.restype = C.c_uint64
-        L.ref_render_rows.argtypes = [C.c_char_p, C.c_int, C.c_int, C.c_int, C.c_uint, C.c_int, C.c_int, C.POINTER(C.c_float)]
-        t0 = time.perf_counter()
-        rays = L.ref_render_rows(b"final", width, height, spp, 1, j0, j0 + rows, None)
-        dt = time.perf_counter() - t0
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import ref_band
+    if ref_band.available():
+        rays, dt = ref_band.render_band((width, height, spp, j0, rows, 1))
         kind = "reference"
     else:
         sys.path.insert(0, os.path.join(ROOT, "tests"))
@@ -69,6 +65,26 @@ def cpu_baseline(width, height, spp):
     return {"value": rays / dt / 1e6, "unit": "Mrays/s", "cores": 1, "kind": kind,
             "sample": f"rows {j0}..{j0 + rows} of {width}x{height}, {spp} spp, final scene: {rays} rays in {dt:.1f} s",
             "samples_per_s": rows * width * spp / dt}
+
+
+def cpu_baseline_multicore(width, height, spp, cores):
+    """Pixel-parallel variant (what main_modern.cpp:172-195 does with OpenMP, but with thread-private random
+    streams): `cores` processes, each rendering its own 24-row band of the same image at the same time."""
+    import multiprocessing as mp
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import ref_band
+    if not ref_band.available():
+        return None
+    rows = 24
+    bands = [(width, height, spp, (height // cores) * k, rows, 100 + k) for k in range(cores)]
+    t0 = time.perf_counter()
+    with mp.get_context("spawn").Pool(cores) as pool:
+        res = pool.map(ref_band.render_band, bands)
+    dt = time.perf_counter() - t0
+    busy = max(r[1] for r in res)
+    rays = sum(r[0] for r in res)
+    return {"value": rays / busy / 1e6, "unit": "Mrays/s", "cores": cores, "kind": "reference",
+            "sample": f"{cores} processes x {rows} rows of {width}x{height}, {spp} spp, final scene: {rays} rays, slowest band {busy:.1f} s (pool wall {dt:.1f} s)"}
 
 
 def main():
@@ -91,6 +107,13 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {args.gpus}")
+    # CPU baselines first, before this process touches the GPU: they start worker processes.
+    cpu_lines = {}
+    if world == 1 and not args.no_cpu_baseline:
+        cpu_lines["cpu_baseline"] = cpu_baseline(1200, 800, 10)
+        multi = cpu_baseline_multicore(1200, 800, 10, min(16, os.cpu_count() or 1))
+        if multi:
+            cpu_lines["cpu_baseline_multicore"] = multi
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the render path has no CPU fallback")
     if args.rehearse_on_one_gpu:
@@ -192,8 +215,7 @@ def main():
                          "kernel": {"megakernel": "k_trace", "wavefront": "k_wf_intersect + k_wf_shade", "pixel": "k_render_mega"}[args.mode], "flop_per_ray": flop_per_ray,
                          "note": "FP32 vector-ALU bound (HBM traffic and MFMA are not on this path); algorithmic flops = rays x (18 x spheres + 150)"},
         }
-        if world == 1 and not args.no_cpu_baseline:
-            line["cpu_baseline"] = cpu_baseline(1200, 800, 10)
+        line.update(cpu_lines)
         checksum = int(img.to(torch.int64).sum().item()) if img is not None else None
         line["image_checksum"] = checksum
         print(json.dumps(line), flush=True)
