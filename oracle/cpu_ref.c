@@ -213,6 +213,8 @@ orc_ray orc_camera_get_ray(const orc_camera *c, float s, float t, float disk_x, 
 }
 
 /* ------------------------------------------------------------------ Color (main.cpp:13-39) */
+static int g_max_depth = 50;     /* the literal 50 of main.cpp:22; settable so that the library's max_depth parameter can be checked */
+void orc_set_max_depth(int d) { g_max_depth = d; }
 orc_vec3 orc_color(const orc_scene *s, orc_ray r, int depth, orc_usrc *u, uint64_t *rays)
 {
     orc_hit rec;
@@ -221,7 +223,7 @@ orc_vec3 orc_color(const orc_scene *s, orc_ray r, int depth, orc_usrc *u, uint64
     if (orc_world_hit(s, r, 0.001f, FLT_MAX, &rec)) {
         orc_ray scattered; orc_vec3 att;
         int i = rec.idx;
-        if (depth < 50 && orc_scatter(s->type[i], V(s->ar[i], s->ag[i], s->ab[i]), s->param[i], r, &rec, u, &att, &scattered))
+        if (depth < g_max_depth && orc_scatter(s->type[i], V(s->ar[i], s->ag[i], s->ab[i]), s->param[i], r, &rec, u, &att, &scattered))
             return mulv(att, orc_color(s, scattered, depth + 1, u, rays));
         return V(0.0f, 0.0f, 0.0f);
     }

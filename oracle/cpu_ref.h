@@ -47,6 +47,7 @@ float orc_metal_fuzz(float fuzz);
 void orc_camera_init(orc_camera *c, orc_vec3 from, orc_vec3 at, orc_vec3 up, float vfov, float aspect, float aperture, float focus);
 orc_ray orc_camera_get_ray(const orc_camera *c, float s, float t, float disk_x, float disk_y);
 orc_vec3 orc_color(const orc_scene *s, orc_ray r, int depth, orc_usrc *u, uint64_t *rays);
+void orc_set_max_depth(int d);   /* depth cap of Color(), 50 in the reference */
 void orc_quantise(const float mean_rgb[3], int out_rgb[3]);
 
 /* Rows j in [j0, j1) (j counts from the bottom like the reference loop), stored top to bottom.

@@ -299,6 +299,33 @@ def test_edge_cases(rt):
     assert one.shape == (1, 1, 3) and r1 >= 4
 
 
+def test_depth_cap_and_second_context(rt):
+    """max_depth other than the reference's 50 against the oracle with the same cap; two contexts side by side."""
+    scene = O.SceneArrays.from_table(O.three_sphere_table(True))
+    ocam = O.three_camera(48, 27)
+    rt.upload_scene(R.three_sphere_table(True))
+    rt.set_camera(R.three_camera(48, 27))
+    other = R.Renderer(0)
+    other.upload_scene(R.final_scene_table())
+    other.set_camera(R.final_camera(48, 27))
+    try:
+        for cap in (1, 3, 7):
+            O.lib().orc_set_max_depth(cap)
+            want, wq, wrays = O.render(scene, ocam, 48, 27, 6, O.usrc_philox(21))
+            for mode in (R.MODE_MEGAKERNEL, R.MODE_WAVEFRONT, R.MODE_PIXEL):
+                rgb, irgb, rays, _ = rt.render(rt.params(48, 27, 6, seed=21, max_depth=cap, mode=mode))
+                assert rays == wrays and same(rgb, want) and np.array_equal(irgb, wq), (cap, mode)
+    finally:
+        O.lib().orc_set_max_depth(50)
+    # the second context renders its own scene unaffected by the first
+    a, _, ra, _ = other.render(other.params(48, 27, 2, seed=1))
+    rt.upload_scene(R.final_scene_table())
+    rt.set_camera(R.final_camera(48, 27))
+    b, _, rb, _ = rt.render(rt.params(48, 27, 2, seed=1))
+    assert ra == rb and same(a, b)
+    other.close()
+
+
 def test_error_behaviour(rt):
     fresh = R.Renderer(0)
     with pytest.raises(R.RtError):
