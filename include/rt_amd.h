@@ -110,6 +110,15 @@ int rt_render_device(rt_context *ctx, const rt_params *p, float *d_rgb_mean, int
  * per Color() invocation, the quantity RenderStats::rays_traced counts, main_modern.cpp:25-28)
  * and the GPU time between the HIP events that bracket its kernels.  Either may be NULL. */
 int rt_render_stats(rt_context *ctx, uint64_t *rays, float *kernel_ms);
+/* The three counters of RenderStats (performance.h:34-37) with the meaning Color() gives them in
+ * main_modern.cpp:23-61: Color() invocations, those whose world->Hit() returned true, and those
+ * whose Scatter() returned true below the depth cap.  Waits for the last rt_render_device on ctx. */
+typedef struct rt_counters {
+    uint64_t rays_traced;
+    uint64_t intersection_tests;
+    uint64_t material_evaluations;
+} rt_counters;
+int rt_render_counters(rt_context *ctx, rt_counters *out);
 /* Host-pointer convenience form: render, copy back, wait. */
 int rt_render(rt_context *ctx, const rt_params *p, float *h_rgb_mean, int32_t *h_irgb,
               uint64_t *rays, float *kernel_ms);
@@ -132,6 +141,16 @@ int rt_scene_grid(uint64_t seed, int half_extent, int max_small, float *table9, 
 int64_t rt_format_ppm(const int32_t *irgb, int width, int height, char *buf, int64_t cap);
 /* Creates/truncates `path` and writes the P3 image. */
 int rt_write_ppm(const char *path, const int32_t *irgb, int width, int height);
+/* The same text produced on the GPU from a device-resident quantised image (the d_irgb of
+ * rt_render_device), so that the only host traffic is the finished text.  d_text: device buffer of `cap`
+ * bytes; *bytes receives the length of the text.  When d_text is NULL or cap is too small nothing is
+ * written, *bytes holds the required capacity and RT_ERR_TOO_LARGE is returned.  The call waits for the
+ * length pass on `stream`; the write pass is enqueued on it and not waited for. */
+int rt_encode_ppm_device(rt_context *ctx, const int32_t *d_irgb, int width, int height, char *d_text,
+                         int64_t cap, int64_t *bytes, void *stream);
+/* rt_encode_ppm_device into a temporary device buffer, one copy to the host, then the file write. */
+int rt_write_ppm_device(rt_context *ctx, const char *path, const int32_t *d_irgb, int width, int height,
+                        void *stream);
 
 /* ---- unit-level entry points: the device functions on arrays -------------------------- */
 /* Each runs the same __device__ function the render kernels call, one element per lane, on host

@@ -215,16 +215,24 @@ orc_ray orc_camera_get_ray(const orc_camera *c, float s, float t, float disk_x, 
 /* ------------------------------------------------------------------ Color (main.cpp:13-39) */
 static int g_max_depth = 50;     /* the literal 50 of main.cpp:22; settable so that the library's max_depth parameter can be checked */
 void orc_set_max_depth(int d) { g_max_depth = d; }
+/* RenderStats as main_modern.cpp:23-61 maintains it: Color() calls, calls whose Hit() was true, calls whose
+ * Scatter() was true below the depth cap. */
+static uint64_t g_counters[3];
+void orc_counters_reset(void) { g_counters[0] = g_counters[1] = g_counters[2] = 0; }
+void orc_counters_get(uint64_t out[3]) { out[0] = g_counters[0]; out[1] = g_counters[1]; out[2] = g_counters[2]; }
 orc_vec3 orc_color(const orc_scene *s, orc_ray r, int depth, orc_usrc *u, uint64_t *rays)
 {
     orc_hit rec;
-    *rays += 1;
+    *rays += 1; g_counters[0] += 1;
     if (u->kind == 2) orc_usrc_slot(u, u->px, u->smp, u->bounce + 1);   /* query k of a sample scatters from slot k */
     if (orc_world_hit(s, r, 0.001f, FLT_MAX, &rec)) {
         orc_ray scattered; orc_vec3 att;
         int i = rec.idx;
-        if (depth < g_max_depth && orc_scatter(s->type[i], V(s->ar[i], s->ag[i], s->ab[i]), s->param[i], r, &rec, u, &att, &scattered))
+        g_counters[1] += 1;
+        if (depth < g_max_depth && orc_scatter(s->type[i], V(s->ar[i], s->ag[i], s->ab[i]), s->param[i], r, &rec, u, &att, &scattered)) {
+            g_counters[2] += 1;
             return mulv(att, orc_color(s, scattered, depth + 1, u, rays));
+        }
         return V(0.0f, 0.0f, 0.0f);
     }
     orc_vec3 ud = unit(r.d);

@@ -47,6 +47,9 @@ float orc_metal_fuzz(float fuzz);
 void orc_camera_init(orc_camera *c, orc_vec3 from, orc_vec3 at, orc_vec3 up, float vfov, float aspect, float aperture, float focus);
 orc_ray orc_camera_get_ray(const orc_camera *c, float s, float t, float disk_x, float disk_y);
 orc_vec3 orc_color(const orc_scene *s, orc_ray r, int depth, orc_usrc *u, uint64_t *rays);
+/* process-wide counters of orc_color: calls, calls that hit, calls that scattered (main_modern.cpp:23-61) */
+void orc_counters_reset(void);
+void orc_counters_get(uint64_t out[3]);
 void orc_set_max_depth(int d);   /* depth cap of Color(), 50 in the reference */
 void orc_quantise(const float mean_rgb[3], int out_rgb[3]);
 

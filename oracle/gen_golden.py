@@ -36,22 +36,33 @@ def render(scene, nx, ny, ns, mode, seed, aperture, bands):
         s = seed if (mode == "philox" or bands == 1) else seed + b
         r = subprocess.run([H, "render", scene, str(nx), str(ny), str(ns), mode, str(s), str(j0), str(j1), str(aperture), out],
                            check=True, capture_output=True, text=True)
-        rays = int(r.stdout.split()[1])
-        return np.fromfile(out, dtype=np.float32).reshape(j1 - j0, nx, 3), rays
+        words = r.stdout.split()               # "rays R hits H"
+        return np.fromfile(out, dtype=np.float32).reshape(j1 - j0, nx, 3), (int(words[1]), int(words[3]))
 
     with ThreadPoolExecutor(max_workers=8) as ex:
         parts = list(ex.map(one, range(bands)))
     # band b covers rows j in [j0, j1) counted from the bottom; images are stored top to bottom
     img = np.concatenate([p[0] for p in reversed(parts)], axis=0)
-    return img, sum(p[1] for p in parts)
+    return img, sum(p[1][0] for p in parts), sum(p[1][1] for p in parts)
 
 
 def main():
+    # --counts: leave the vectors and images alone; re-render the reproducible images (keyed stream, or
+    # aperture 0 so that the unseedable lens generator is multiplied by zero), check that they equal
+    # the stored ones bit for bit and refresh only the counters in images.json.
+    counts_only = "--counts" in sys.argv[1:]
     os.makedirs(G, exist_ok=True)
-    subprocess.run([H, "scene", os.path.join(G, "scene_final.txt")], check=True)
-    subprocess.run([H, "units", G], check=True)
-    subprocess.run([H, "paths", os.path.join(G, "color_paths.txt"), "400"], check=True)
     meta = {}
+    if counts_only:
+        with open(os.path.join(G, "images.json")) as f:
+            meta = json.load(f)
+    else:
+        subprocess.run([H, "scene", os.path.join(G, "scene_final.txt")], check=True)
+        subprocess.run([H, "units", G], check=True)
+        subprocess.run([H, "paths", os.path.join(G, "color_paths.txt"), "400"], check=True)
+    subprocess.run([H, "tiles", os.path.join(G, "tiles.txt")], check=True)
+    with open(os.path.join(G, "stats_report.txt"), "w") as f:
+        f.write(subprocess.run([H, "stats"], check=True, capture_output=True, text=True).stdout)
     jobs = [
         # name, scene, nx, ny, ns, mode, seed, aperture(-1 = scene default), bands
         ("libc_final_48x32x3_ap0", "final", 48, 32, 3, "libc", 0, 0.0, 1),
@@ -63,9 +74,18 @@ def main():
         ("hispp_three_100x56x1024", "three", 100, 56, 1024, "libc", 200, -1, 8),
     ]
     for name, scene, nx, ny, ns, mode, seed, ap, bands in jobs:
-        img, rays = render(scene, nx, ny, ns, mode, seed, ap, bands)
-        np.save(os.path.join(G, f"img_{name}.npy"), img)
+        reproducible = mode == "philox" or (ap == 0.0 and bands == 1)
+        if counts_only and not reproducible:
+            continue
+        img, rays, hits = render(scene, nx, ny, ns, mode, seed, ap, bands)
+        if counts_only:
+            assert np.array_equal(img.view(np.uint32), np.load(os.path.join(G, f"img_{name}.npy")).view(np.uint32)), name
+        else:
+            np.save(os.path.join(G, f"img_{name}.npy"), img)
+        # RenderStats semantics (main_modern.cpp:23-61): every Color() call beyond a sample's first one
+        # follows a successful Scatter below the depth cap
         meta[name] = dict(scene=scene, nx=nx, ny=ny, ns=ns, mode=mode, seed=seed, aperture=ap, bands=bands, rays=rays,
+                          hits=hits, scatters=rays - nx * ny * ns,
                           mean_rgb=[float(x) for x in img.reshape(-1, 3).mean(axis=0)])
         print(name, rays, meta[name]["mean_rgb"], flush=True)
     with open(os.path.join(G, "images.json"), "w") as f:

@@ -20,6 +20,7 @@
 #define main rt_reference_main
 #include "main.cpp"
 #undef main
+#include "appsrc/include/Math/performance.h"   // RenderStats / create_tiles of the multi-threaded variant
 
 extern "C" {
 #include "cpu_ref.h"   // only for orc_philox4x32_10 (pinned by Random123 known-answer vectors)
@@ -65,16 +66,19 @@ static float philox_word(uint32_t px, uint32_t smp, uint32_t bounce, uint32_t gr
     return (float)(out[w] >> 8) * (1.0f / 16777216.0f);
 }
 
-// World wrapper: counts closest-hit queries (= Color() invocations = "rays") and, in Philox
+// World wrapper: counts closest-hit queries (= Color() invocations = "rays") and how many of them hit
+// (the counter main_modern.cpp:34-37 calls intersection_tests) and, in Philox
 // mode, advances the bounce slot: the k-th query of a sample is depth k-1, and the scatter that
 // follows it draws from slot bounce = k.
 struct CountingWorld : public Hittable {
-    Hittable* inner; mutable uint64_t rays = 0;
+    Hittable* inner; mutable uint64_t rays = 0, hits = 0;
     explicit CountingWorld(Hittable* w) : inner(w) {}
     bool Hit(const Ray& r, float tmin, float tmax, HitRecord& rec) const override {
         ++rays;
         if (g_mode == RAND_PHILOX) { g_bounce += 1; g_draw = 0; }
-        return inner->Hit(r, tmin, tmax, rec);
+        const bool h = inner->Hit(r, tmin, tmax, rec);
+        hits += h ? 1u : 0u;
+        return h;
     }
 };
 
@@ -292,7 +296,7 @@ static void gen_paths(const char* path, int n)
 //                drawn from slot (pixel, sample, 0) (words named in the loop below) and applied with the expression of
 //                camera.cpp:48-52 on the reference Camera's public fields, because the reference's
 //                own lens generator (camera.cpp:33-35) cannot be seeded.
-struct RenderOut { std::vector<float> rgb; uint64_t rays; };
+struct RenderOut { std::vector<float> rgb; uint64_t rays, hits; };
 static RenderOut render(const std::string& scene, int nx, int ny, int ns, const std::string& mode, uint64_t seed, int j0, int j1, float aperture_override)
 {
     srand(1);   // fresh-process generator state
@@ -341,7 +345,7 @@ static RenderOut render(const std::string& scene, int nx, int ny, int ns, const 
         }
     }
     g_mode = RAND_LIBC;
-    out.rays = world.rays;
+    out.rays = world.rays; out.hits = world.hits;
     return out;
 }
 
@@ -367,13 +371,31 @@ int main(int argc, char** argv)
         gen_camera((d + "/camera.txt").c_str());
         return 0;
     }
+    if (cmd == "tiles") {
+        // create_tiles (performance.h:143-155) for a few image sizes: "w h samples tile_size count" then one "x y w h s" line per tile
+        FILE* f = fopen(argv[2], "w");
+        const int cases[][4] = { { 2560, 1440, 10, 64 }, { 1200, 800, 10, 64 }, { 100, 70, 3, 32 }, { 64, 64, 1, 64 }, { 65, 1, 2, 64 }, { 7, 200, 5, 16 } };
+        for (const auto& c : cases) {
+            const std::vector<RenderTile> t = create_tiles(c[0], c[1], c[2], c[3]);
+            fprintf(f, "%d %d %d %d %zu\n", c[0], c[1], c[2], c[3], t.size());
+            for (const RenderTile& r : t) fprintf(f, "%d %d %d %d %d\n", r.x_start, r.y_start, r.width, r.height, r.samples_per_pixel);
+        }
+        fclose(f);
+        return 0;
+    }
+    if (cmd == "stats") {
+        // RenderStats::print_stats (performance.h:51-59) on fixed numbers, to stdout
+        RenderStats st; st.rays_traced = 98765432; st.intersection_tests = 61234567; st.material_evaluations = 51234567; st.total_time_ms = 1234.5678;
+        st.print_stats();
+        return 0;
+    }
     if (cmd == "paths") { gen_paths(argv[2], atoi(argv[3])); return 0; }
     if (cmd == "render") {
         // render <scene> <nx> <ny> <ns> <libc|philox> <seed> <j0> <j1> <aperture|-1> <out.f32>
         if (argc < 12) { fprintf(stderr, "render: missing args\n"); return 2; }
         RenderOut r = render(argv[2], atoi(argv[3]), atoi(argv[4]), atoi(argv[5]), argv[6], strtoull(argv[7], 0, 10), atoi(argv[8]), atoi(argv[9]), (float)atof(argv[10]));
         FILE* f = fopen(argv[11], "wb"); fwrite(r.rgb.data(), sizeof(float), r.rgb.size(), f); fclose(f);
-        printf("rays %llu\n", (unsigned long long)r.rays);
+        printf("rays %llu hits %llu\n", (unsigned long long)r.rays, (unsigned long long)r.hits);
         return 0;
     }
     fprintf(stderr, "unknown command\n"); return 2;

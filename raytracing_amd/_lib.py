@@ -13,8 +13,8 @@ LAMBERTIAN, METAL, DIELECTRIC = 0, 1, 2
 
 # every symbol include/rt_amd.h declares
 EXPORTS = ["rt_device_count", "rt_create", "rt_destroy", "rt_last_error", "rt_upload_scene", "rt_set_camera",
-           "rt_owned_rows", "rt_owned_pixels", "rt_render_device", "rt_render_stats", "rt_render",
-           "rt_scene_grid", "rt_format_ppm", "rt_write_ppm", "rt_test_sphere_hit", "rt_test_scatter", "rt_test_get_ray",
+           "rt_owned_rows", "rt_owned_pixels", "rt_render_device", "rt_render_stats", "rt_render_counters", "rt_render",
+           "rt_scene_grid", "rt_format_ppm", "rt_write_ppm", "rt_encode_ppm_device", "rt_write_ppm_device", "rt_test_sphere_hit", "rt_test_scatter", "rt_test_get_ray",
            "rt_test_philox"]
 
 
@@ -36,6 +36,11 @@ class Params(C.Structure):
     _fields_ = [("width", C.c_int32), ("height", C.c_int32), ("spp", C.c_int32), ("max_depth", C.c_int32),
                 ("tmin", C.c_float), ("seed", C.c_uint64), ("band_rows", C.c_int32), ("band_first", C.c_int32),
                 ("band_step", C.c_int32), ("mode", C.c_int32)]
+
+
+class Counters(C.Structure):
+    """rt_counters: RenderStats' three counters (performance.h:34-37)."""
+    _fields_ = [("rays_traced", C.c_uint64), ("intersection_tests", C.c_uint64), ("material_evaluations", C.c_uint64)]
 
 
 _lib = None
@@ -65,11 +70,14 @@ def load_library():
     L.rt_owned_pixels.restype = C.c_int64
     L.rt_render_device.argtypes = [vp, C.POINTER(Params), vp, vp, vp]
     L.rt_render_stats.argtypes = [vp, C.POINTER(C.c_uint64), C.POINTER(C.c_float)]
+    L.rt_render_counters.argtypes = [vp, C.POINTER(Counters)]
     L.rt_render.argtypes = [vp, C.POINTER(Params), fp, ip, C.POINTER(C.c_uint64), C.POINTER(C.c_float)]
     L.rt_scene_grid.argtypes = [C.c_uint64, C.c_int, C.c_int, fp, C.c_int, C.POINTER(C.c_int)]
     L.rt_format_ppm.argtypes = [ip, C.c_int, C.c_int, C.c_char_p, C.c_int64]
     L.rt_format_ppm.restype = C.c_int64
     L.rt_write_ppm.argtypes = [C.c_char_p, ip, C.c_int, C.c_int]
+    L.rt_encode_ppm_device.argtypes = [vp, vp, C.c_int, C.c_int, vp, C.c_int64, C.POINTER(C.c_int64), vp]
+    L.rt_write_ppm_device.argtypes = [vp, C.c_char_p, vp, C.c_int, C.c_int, vp]
     L.rt_test_sphere_hit.argtypes = [vp, C.c_int, fp, fp, fp, fp, fp, fp, ip, fp, fp, fp]
     L.rt_test_scatter.argtypes = [vp, C.c_int, ip, fp, fp, fp, fp, fp, fp, ip, C.c_int, ip, fp, fp, fp, ip]
     L.rt_test_get_ray.argtypes = [vp, C.c_int, C.POINTER(CameraPod), fp, fp, fp, fp, fp]
@@ -207,6 +215,25 @@ class Renderer:
         rays, ms = C.c_uint64(0), C.c_float(0)
         self._check(self._L.rt_render_stats(self._ctx, C.byref(rays), C.byref(ms)))
         return rays.value, ms.value
+
+    def counters(self):
+        """(rays_traced, intersection_tests, material_evaluations) of the last render."""
+        c = Counters()
+        self._check(self._L.rt_render_counters(self._ctx, C.byref(c)))
+        return int(c.rays_traced), int(c.intersection_tests), int(c.material_evaluations)
+
+    def encode_ppm_device(self, d_irgb, width, height, d_text=0, cap=0, stream=0):
+        """P3 text of a device-resident int32 image, written to device memory.  Returns the text length;
+        with d_text = 0 only the length is computed."""
+        n = C.c_int64(0)
+        rc = self._L.rt_encode_ppm_device(self._ctx, C.c_void_p(d_irgb), width, height, C.c_void_p(d_text or None), cap,
+                                          C.byref(n), C.c_void_p(stream or None))
+        if rc != 0 and not (rc == -5 and not d_text):
+            self._check(rc)
+        return n.value
+
+    def write_ppm_device(self, path, d_irgb, width, height, stream=0):
+        self._check(self._L.rt_write_ppm_device(self._ctx, os.fsencode(path), C.c_void_p(d_irgb), width, height, C.c_void_p(stream or None)))
 
     # ---- unit-level entry points -------------------------------------------------------
     def test_sphere_hit(self, ray_o, ray_d, center, radius, tmin, tmax):

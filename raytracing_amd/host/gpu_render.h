@@ -57,25 +57,84 @@ inline rt_camera_pod ToPod(const Camera& c)
 
 struct RenderResult { std::vector<int32_t> irgb; uint64_t rays = 0; float kernel_ms = 0.0f; };
 
+// A GPU context holding one flattened scene and one camera; renders whole images or row bands of them.
+class GpuRenderer {
+public:
+    GpuRenderer(const Hittable* world, const Camera& cam, int device = 0)
+    {
+        if (rt_create(device, &m_ctx) != RT_OK) throw std::runtime_error(std::string("rt_create: ") + rt_last_error(nullptr));
+        try {
+            const FlatScene f = Flatten(world);
+            Check(rt_upload_scene(m_ctx, f.size(), f.cx.data(), f.cy.data(), f.cz.data(), f.radius.data(), f.material.data(), f.albedo.data(), f.param.data()), "rt_upload_scene");
+            const rt_camera_pod pod = ToPod(cam);
+            Check(rt_set_camera(m_ctx, &pod), "rt_set_camera");
+        } catch (...) { rt_destroy(m_ctx); throw; }
+    }
+    ~GpuRenderer() { rt_destroy(m_ctx); }
+    GpuRenderer(const GpuRenderer&) = delete;
+    GpuRenderer& operator=(const GpuRenderer&) = delete;
+
+    static rt_params Params(int nx, int ny, int ns, uint64_t seed)
+    {
+        rt_params p{};
+        p.width = nx; p.height = ny; p.spp = ns; p.max_depth = 50; p.tmin = 0.001f; p.seed = seed;
+        p.band_rows = ny; p.band_first = 0; p.band_step = 1; p.mode = RT_MODE_MEGAKERNEL;
+        return p;
+    }
+
+    // The bands p selects; irgb must hold 3 * rt_owned_pixels(&p) ints.  Returns the kernel time in ms and
+    // adds the call's counters to *counters when given.
+    float Render(const rt_params& p, int32_t* irgb, rt_counters* counters = nullptr)
+    {
+        float ms = 0.0f;
+        Check(rt_render(m_ctx, &p, nullptr, irgb, nullptr, &ms), "rt_render");
+        if (counters) {
+            rt_counters c{};
+            Check(rt_render_counters(m_ctx, &c), "rt_render_counters");
+            counters->rays_traced += c.rays_traced;
+            counters->intersection_tests += c.intersection_tests;
+            counters->material_evaluations += c.material_evaluations;
+        }
+        return ms;
+    }
+
+    // Progressive form: the image is rendered in bands of band_rows rows, top to bottom; after each band
+    // on_band(first_row, rows, irgb_of_the_band) is called, so a caller can show or store finished rows
+    // while the rest is still being rendered.  Because every uniform is keyed on the pixel, the rows are
+    // the same as those of a single whole-image call.
+    template <class OnBand>
+    float RenderProgressive(int nx, int ny, int ns, uint64_t seed, int band_rows, rt_counters* counters, OnBand on_band)
+    {
+        if (band_rows <= 0) throw std::invalid_argument("RenderProgressive: band_rows must be positive");
+        const int bands = (ny + band_rows - 1) / band_rows;
+        std::vector<int32_t> band((size_t)band_rows * nx * 3);
+        float total_ms = 0.0f;
+        for (int b = 0; b < bands; ++b) {
+            rt_params p = Params(nx, ny, ns, seed);
+            p.band_rows = band_rows; p.band_first = b; p.band_step = bands;     // exactly band b
+            total_ms += Render(p, band.data(), counters);
+            on_band(b * band_rows, (int)rt_owned_rows(&p), band.data());
+        }
+        return total_ms;
+    }
+
+private:
+    void Check(int rc, const char* what) const
+    {
+        if (rc != RT_OK) throw std::runtime_error(std::string(what) + ": " + rt_last_error(m_ctx));
+    }
+    rt_context* m_ctx = nullptr;
+};
+
 // Replaces the nested loop of main.cpp:118-141 for the whole image on GPU `device`.
 inline RenderResult RenderOnGpu(const Hittable* world, const Camera& cam, int nx, int ny, int ns, uint64_t seed = 0, int device = 0)
 {
-    rt_context* ctx = nullptr;
-    if (rt_create(device, &ctx) != RT_OK) throw std::runtime_error(std::string("rt_create: ") + rt_last_error(nullptr));
-    auto check = [&](int rc, const char* what) {
-        if (rc != RT_OK) { std::string msg = std::string(what) + ": " + rt_last_error(ctx); rt_destroy(ctx); throw std::runtime_error(msg); }
-    };
-    const FlatScene f = Flatten(world);
-    check(rt_upload_scene(ctx, f.size(), f.cx.data(), f.cy.data(), f.cz.data(), f.radius.data(), f.material.data(), f.albedo.data(), f.param.data()), "rt_upload_scene");
-    const rt_camera_pod pod = ToPod(cam);
-    check(rt_set_camera(ctx, &pod), "rt_set_camera");
-    rt_params p{};
-    p.width = nx; p.height = ny; p.spp = ns; p.max_depth = 50; p.tmin = 0.001f; p.seed = seed;
-    p.band_rows = ny; p.band_first = 0; p.band_step = 1; p.mode = RT_MODE_MEGAKERNEL;
+    GpuRenderer gpu(world, cam, device);
     RenderResult out;
     out.irgb.resize((size_t)nx * ny * 3);
-    check(rt_render(ctx, &p, nullptr, out.irgb.data(), &out.rays, &out.kernel_ms), "rt_render");
-    rt_destroy(ctx);
+    rt_counters c{};
+    out.kernel_ms = gpu.Render(GpuRenderer::Params(nx, ny, ns, seed), out.irgb.data(), &c);
+    out.rays = c.rays_traced;
     return out;
 }
 

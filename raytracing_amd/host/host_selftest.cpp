@@ -10,6 +10,7 @@
 #include <string>
 #include <vector>
 #include "gpu_render.h"
+#include "performance.h"
 #include "scene.h"
 
 static std::vector<int> g_replay; static size_t g_pos = 0; static bool g_use_replay = false;
@@ -95,6 +96,32 @@ int main(int argc, char** argv)
             delete m; ++n;
         }
         std::printf("ok scatter %d\n", n);
+    }
+    {   // create_tiles (performance.h:143-155)
+        const auto t = rows(g + "/tiles.txt");
+        size_t at = 0; int cases = 0;
+        while (at < t.size()) {
+            const auto& h = t[at++];
+            REQUIRE(h.size() == 5);
+            const std::vector<RenderTile> tiles = create_tiles(std::atoi(h[0].c_str()), std::atoi(h[1].c_str()), std::atoi(h[2].c_str()), std::atoi(h[3].c_str()));
+            REQUIRE(tiles.size() == (size_t)std::atol(h[4].c_str()) && at + tiles.size() <= t.size());
+            for (const RenderTile& r : tiles) {
+                const auto& w = t[at++];
+                REQUIRE(r.x_start == std::atoi(w[0].c_str()) && r.y_start == std::atoi(w[1].c_str()) && r.width == std::atoi(w[2].c_str()) &&
+                        r.height == std::atoi(w[3].c_str()) && r.samples_per_pixel == std::atoi(w[4].c_str()));
+            }
+            ++cases;
+        }
+        std::printf("ok tiles %d\n", cases);
+    }
+    {   // RenderStats::print_stats (performance.h:51-59): the caller compares what follows with the reference's text
+        RenderStats st; st.rays_traced = 98765432; st.intersection_tests = 61234567; st.material_evaluations = 51234567; st.total_time_ms = 1234.5678;
+        std::printf("stats report follows\n");
+        st.print_stats();
+        st.reset();
+        REQUIRE(st.rays_traced.load() == 0 && st.total_time_ms == 0.0);
+        PerformanceTimer timer; timer.begin();
+        REQUIRE(timer.elapsed_ms() >= 0.0 && timer.elapsed_seconds() < 60.0);
     }
     return 0;
 }

@@ -92,6 +92,8 @@ def _proto(L):
     L.orc_random_scene.restype = C.c_int
     L.orc_random_scene.argtypes = [C.POINTER(USrc)] + [C.POINTER(C.c_float)] * 4 + [C.POINTER(C.c_int)] + [C.POINTER(C.c_float)] * 4
     L.orc_quantise.argtypes = [C.POINTER(C.c_float), C.POINTER(C.c_int)]
+    L.orc_counters_reset.argtypes = []
+    L.orc_counters_get.argtypes = [C.POINTER(C.c_uint64)]
 
 
 class SceneArrays:
@@ -165,3 +167,13 @@ def render(scene, cam, nx, ny, ns, usrc, j0=0, j1=None, fast=False):
     rays = lib(fast).orc_render(C.byref(scene.c), C.byref(cam), nx, ny, ns, C.byref(usrc), j0, j1,
                                 rgb.ctypes.data_as(C.POINTER(C.c_float)), irgb.ctypes.data_as(C.POINTER(C.c_int)))
     return rgb, irgb, int(rays)
+
+
+def render_counted(scene, cam, nx, ny, ns, usrc, j0=0, j1=None):
+    """render() plus the RenderStats counters (rays_traced, intersection_tests, material_evaluations)."""
+    L = lib()
+    L.orc_counters_reset()
+    rgb, irgb, rays = render(scene, cam, nx, ny, ns, usrc, j0, j1)
+    c = (C.c_uint64 * 3)()
+    L.orc_counters_get(c)
+    return rgb, irgb, rays, (int(c[0]), int(c[1]), int(c[2]))

@@ -142,6 +142,8 @@ def test_render_is_bit_identical_to_reference_image(rt, name, mode):
     _setup(rt, m)
     rgb, irgb, rays, ms = rt.render(rt.params(m["nx"], m["ny"], m["ns"], seed=m["seed"], mode=mode))
     assert rays == m["rays"]
+    # RenderStats of main_modern.cpp:23-61 as counted by the reference build
+    assert rt.counters() == (m["rays"], m["hits"], m["scatters"])
     assert mismatch(rgb, want) == 0
     q = np.zeros_like(irgb)
     for y in range(rgb.shape[0]):
@@ -341,3 +343,55 @@ def test_error_behaviour(rt):
     fresh.close()
     with pytest.raises(R.RtError):
         R.Renderer(99)
+
+
+def test_ppm_text_encoded_on_the_gpu_equals_the_host_formatter(rt, tmp_path):
+    """output.ppm (main.cpp:95-97,143-144) produced from the device-resident image: same bytes as the host formatter."""
+    import torch
+    rng = np.random.default_rng(11)
+    cases = []
+    # every value 0..255 and the values a NaN or an unclamped radiance can produce
+    special = np.array([0, 9, 10, 99, 100, 255, 256, 999, 1000, 65535, -1, -10, -2147483648, 2147483647, 1000000000, 999999999], dtype=np.int32)
+    for (w, h) in [(1, 1), (3, 1), (7, 5), (341, 3), (1024, 1), (1025, 1), (257, 129), (1200, 800)]:
+        img = rng.integers(0, 256, size=(h, w, 3), dtype=np.int32)
+        if w * h >= 16:
+            idx = rng.integers(0, w * h * 3, size=min(64, w * h))
+            img.reshape(-1)[idx] = special[rng.integers(0, len(special), size=len(idx))]
+        cases.append(img)
+    cases.append(np.full((33, 65, 3), -2147483648, dtype=np.int32))      # longest possible lines
+    cases.append(np.zeros((64, 64, 3), dtype=np.int32))                  # shortest
+    for img in cases:
+        h, w = img.shape[0], img.shape[1]
+        want = R.format_ppm(img)
+        d_img = torch.from_numpy(img).cuda()
+        need = rt.encode_ppm_device(d_img.data_ptr(), w, h)
+        assert need == len(want)
+        # a text buffer at an odd address, guarded on both sides
+        d_text = torch.full((need + 64,), 0x7e, dtype=torch.uint8, device="cuda")
+        for lead in (0, 1, 2, 3):
+            d_text.fill_(0x7e)
+            got_len = rt.encode_ppm_device(d_img.data_ptr(), w, h, d_text.data_ptr() + 16 + lead, need)
+            torch.cuda.synchronize()
+            host = d_text.cpu().numpy()
+            assert got_len == need
+            assert host[16 + lead:16 + lead + need].tobytes() == want
+            assert (host[:16 + lead] == 0x7e).all() and (host[16 + lead + need:] == 0x7e).all()
+        # capacity one byte short: nothing written, the need reported
+        d_text.fill_(0x7e)
+        with pytest.raises(R.RtError) as e:
+            rt.encode_ppm_device(d_img.data_ptr(), w, h, d_text.data_ptr(), need - 1)
+        assert e.value.code == -5
+        torch.cuda.synchronize()
+        assert (d_text.cpu().numpy() == 0x7e).all()
+    # file form, from a rendered image
+    rt.upload_scene(R.final_scene_table())
+    rt.set_camera(R.final_camera(96, 64))
+    p = rt.params(96, 64, 2, seed=4)
+    d_irgb = torch.zeros((64, 96, 3), dtype=torch.int32, device="cuda")
+    rt.render_device(p, 0, d_irgb.data_ptr())
+    rt.stats()
+    path = str(tmp_path / "gpu.ppm")
+    rt.write_ppm_device(path, d_irgb.data_ptr(), 96, 64)
+    assert open(path, "rb").read() == R.format_ppm(d_irgb.cpu().numpy())
+    with pytest.raises(R.RtError):
+        rt.write_ppm_device("/nonexistent_dir/x.ppm", d_irgb.data_ptr(), 96, 64)

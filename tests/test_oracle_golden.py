@@ -193,8 +193,10 @@ def test_keyed_render_is_bit_identical_to_reference(name):
     m = _meta()[name]
     want = np.load(os.path.join(G, f"img_{name}.npy"))
     scene, cam = _scene_cam(m)
-    rgb, irgb, rays = O.render(scene, cam, m["nx"], m["ny"], m["ns"], O.usrc_philox(m["seed"]))
+    rgb, irgb, rays, counters = O.render_counted(scene, cam, m["nx"], m["ny"], m["ns"], O.usrc_philox(m["seed"]))
     assert rays == m["rays"]
+    # RenderStats of main_modern.cpp:23-61: Color() calls, calls that hit, calls that scattered
+    assert counters == (m["rays"], m["hits"], m["scatters"])
     assert same(rgb, want)
     assert np.isfinite(rgb).all()
 
