@@ -87,6 +87,38 @@ def cpu_baseline_multicore(width, height, spp, cores):
             "sample": f"{cores} processes x {rows} rows of {width}x{height}, {spp} spp, final scene: {rays} rays, slowest band {busy:.1f} s (pool wall {dt:.1f} s)"}
 
 
+def ppm_encode_report(rt, img):
+    """The step after the render loop (output.ppm, main.cpp:91-97,143-147), outside the timed region: ASCII P3 text
+    of the finished image produced on the GPU (rt_encode_ppm_device), next to the single-pass host formatter."""
+    h, w = img.shape[0], img.shape[1]
+    img = img.contiguous()
+    need = rt.encode_ppm_device(img.data_ptr(), w, h)
+    text = torch.empty(need + 8, dtype=torch.uint8, device=img.device)
+    stream = torch.cuda.current_stream().cuda_stream
+    rt.encode_ppm_device(img.data_ptr(), w, h, text.data_ptr(), need, stream)
+    torch.cuda.synchronize()
+    reps = 5
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        rt.encode_ppm_device(img.data_ptr(), w, h, text.data_ptr(), need, stream)
+    torch.cuda.synchronize()
+    gpu_ms = (time.perf_counter() - t0) / reps * 1e3
+    pinned = torch.empty(need, dtype=torch.uint8, pin_memory=True)
+    t0 = time.perf_counter()
+    pinned.copy_(text[:need]); torch.cuda.synchronize()
+    copy_ms = (time.perf_counter() - t0) * 1e3
+    host_img = img.cpu().numpy().reshape(-1)
+    L = R.load_library()
+    cap = 32 + w * h * 36
+    buf = (C.c_char * cap)()
+    t0 = time.perf_counter()
+    n = L.rt_format_ppm(host_img.ctypes.data_as(C.POINTER(C.c_int32)), w, h, buf, cap)
+    host_ms = (time.perf_counter() - t0) * 1e3
+    same = bytes(buf[:n]) == pinned.numpy().tobytes()
+    return {"text_bytes": need, "gpu_encode_ms": gpu_ms, "text_copy_to_host_ms": copy_ms, "host_formatter_ms": host_ms,
+            "identical": bool(same), "note": "three kernels (length, scan, write) including the host wait for the length; not part of the timed region"}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -218,6 +250,8 @@ def main():
         line.update(cpu_lines)
         checksum = int(img.to(torch.int64).sum().item()) if img is not None else None
         line["image_checksum"] = checksum
+        if img is not None and img.is_cuda:
+            line["ppm_encode"] = ppm_encode_report(rt, img)
         print(json.dumps(line), flush=True)
     if world > 1:
         dist.destroy_process_group()

@@ -199,7 +199,8 @@ struct TraceArgs {
     float* samples;                       // [total_items][3]
     unsigned long long* ray_counter;
     unsigned int* work_counter;
-    float* staging;                       // per wave: 8 rows (o, d, pixel, sample) of kChunkItems pre-generated camera rays
+    float* staging;                       // per wave: kStagingRows rows (o, d, pixel, sample, sample-buffer slot) of kChunkItems pre-generated camera rays
+    const uint32_t* tile_order;           // work order of the tiles (see decode_item); may be null
     uint16_t* stacks; uint32_t stack_stride;   // hit-index stacks in HBM: entry k of lane g at stacks[k * stack_stride + g]
 };
 
@@ -207,6 +208,9 @@ struct TraceArgs {
 // main loop into g_section_ticks.  Never enabled in the shipped library (mark() is empty there).
 #ifdef RT_SECTION_TIMERS
 __device__ unsigned long long g_section_ticks[8];
+// per wave of the last k_trace launch: s_memrealtime (100 MHz, common to all XCDs) at entry, when the wave first found the work counter dry, at exit;
+// and how many trips of the main loop it made after that point
+__device__ unsigned long long g_wave_times[6][8192];      // rows 4, 5: trips made with the sparse sweep, ticks spent in those trips (whole trip)
 struct SecTimer {
     unsigned long long acc[8]; unsigned long long last;
     __device__ __forceinline__ void start() { for (int k = 0; k < 8; ++k) acc[k] = 0; last = __builtin_amdgcn_s_memtime(); }
@@ -221,6 +225,7 @@ struct SecTimer {
 };
 #endif
 static constexpr int kChunkItems = 512;
+static constexpr int kStagingRows = 9;
 static constexpr int kTraceBlock = 512;         // 8 waves share one LDS copy of the scene records
 __device__ __forceinline__ float staged_load(const float* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 static constexpr int kSuperChunkWords = 16;                     // 32-sphere mask words kept per lane between exact passes (512 spheres)
@@ -394,6 +399,59 @@ __device__ __forceinline__ void closest_hit(const RayD& ray, float tmin, const S
     }
 }
 
+// The same closest-hit query for a wave that holds only a few live paths (the tail of a launch, when the work
+// counter has run dry): instead of one ray per lane and a loop over the spheres, the live rays are taken one
+// at a time and the SPHERES are spread over the 64 lanes (sphere k on lane k mod 64), followed by a wave
+// reduction.  A sweep for a sparse wave costs as many issue slots as one for a full wave, and a lone wave issues
+// slowly, so this shortens the bounces of the last long paths several times over.  The result is the same
+// (sphere, t): HittableList::Hit's answer is the smallest accepted root over all spheres with ties going to the
+// lower index (hittablelist.cpp:21-29 with sphere.cpp:27-50: for one sphere the accepted root under a running
+// bound c is its first root above tmin, if below c), which does not depend on how the spheres are partitioned.
+constexpr int kFewPaths = 8;
+template <bool kLds>
+__device__ __forceinline__ void closest_hit_few(const RayD& ray, float tmin, const SweepScene& sw, const float4* s_geom,
+                                                unsigned long long live, int lane, float& closest, int& hit)
+{
+    while (live != 0ull) {
+        const int src = __builtin_ctzll(live);
+        live &= live - 1ull;
+        RayD r;
+        r.o = mk(__builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, ray.o.x), src)),
+                 __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, ray.o.y), src)),
+                 __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, ray.o.z), src)));
+        r.d = mk(__builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, ray.d.x), src)),
+                 __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, ray.d.y), src)),
+                 __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, ray.d.z), src)));
+        const float qa = dot(r.d, r.d);
+        float best = FLT_MAX; int best_k = -1;
+        for (int base = 0; base < sw.n; base += 64) {
+            const int k = base + lane;
+            float b = 0.0f, desc = -1.0f;
+            if (k < sw.n) {
+                const float4 g = kLds ? s_geom[k] : sw.geom[k];
+                const V3 oc = r.o - mk(g.x, g.y, g.z);
+                b = dot(oc, r.d);
+                const float cc = dot(oc, oc) - g.w;
+                desc = b * b - qa * cc;
+            }
+            if (__any(desc > 0.0f)) {
+                if (desc > 0.0f) {
+                    const float sq = sqrtf(desc);
+                    float temp = (-b - sq) / qa;
+                    if (!(temp < best && temp > tmin)) temp = (-b + sq) / qa;
+                    if (temp < best && temp > tmin) { best = temp; best_k = k; }
+                }
+            }
+        }
+        // wave minimum of (t, index): smaller t wins, equal t goes to the lower index
+        for (int off = 1; off < 64; off <<= 1) {
+            const float ot = __shfl_xor(best, off); const int ok = __shfl_xor(best_k, off);
+            if (ot < best || (ot == best && (unsigned)ok < (unsigned)best_k)) { best = ot; best_k = ok; }
+        }
+        if (lane == src) { closest = best; hit = best_k; }
+    }
+}
+
 // ============================================================================ shading step of Color()
 // One level of the recursion main.cpp:13-39 for a ray whose closest hit is known.  Returns true when the
 // path has ended (sample = its radiance); otherwise ray/depth are advanced and the hit index is pushed on
@@ -436,11 +494,17 @@ __device__ __forceinline__ bool shade_step(RayD& ray, int& depth, float closest,
 // sample, then pixel by pixel inside the 8x8 tile: item = (tile * s_count + s_rel) * 64 + row_in_tile * 8 +
 // col_in_tile, so 512 consecutive items are eight samples of ONE tile.  Returns false for the padding pixels
 // of edge tiles.
-struct ItemGeometry { int width, height, band_rows, band_first, band_step, owned_rows, tiles_x; uint32_t Q; int s_begin, s_count; };
-__device__ __forceinline__ bool decode_item(const ItemGeometry& ig, uint32_t item, uint32_t& pix, uint32_t& smp, int& i, int& j)
+//
+// tile_order (optional) is a permutation of the tiles: work position `tile` is image tile tile_order[tile], so
+// that the order in which tiles are WORKED on can differ from where their samples are STORED.  `store` is the
+// item number in image-tile order, i.e. the slot of the sample buffer.
+struct ItemGeometry { int width, height, band_rows, band_first, band_step, owned_rows, tiles_x; uint32_t Q; int s_begin, s_count; const uint32_t* tile_order; };
+__device__ __forceinline__ bool decode_item(const ItemGeometry& ig, uint32_t item, uint32_t& pix, uint32_t& smp, int& i, int& j, uint32_t& store)
 {
     const uint32_t ts = item >> 6, l = item & 63u;
-    const uint32_t tile = ts / (uint32_t)ig.s_count, s_rel = ts - tile * (uint32_t)ig.s_count;
+    const uint32_t work_tile = ts / (uint32_t)ig.s_count, s_rel = ts - work_tile * (uint32_t)ig.s_count;
+    const uint32_t tile = ig.tile_order ? ig.tile_order[work_tile] : work_tile;
+    store = ((tile * (uint32_t)ig.s_count + s_rel) << 6) + l;
     const int ty = (int)(tile / (uint32_t)ig.tiles_x), tx = (int)(tile - (uint32_t)ty * (uint32_t)ig.tiles_x);
     i = tx * 8 + (int)(l & 7u);
     const int r = ty * 8 + (int)(l >> 3);
@@ -450,6 +514,96 @@ __device__ __forceinline__ bool decode_item(const ItemGeometry& ig, uint32_t ite
     pix = (uint32_t)j * (uint32_t)ig.width + (uint32_t)i;
     smp = (uint32_t)ig.s_begin + s_rel;
     return true;
+}
+
+// ============================================================================ work order of the tiles
+// A persistent wave keeps all its lanes busy only while there are items left to hand out; once the counter
+// runs dry every wave drains the paths it still holds, and a wave with one 50-bounce path left costs as many
+// issue slots per bounce as a full one.  What is in flight at that moment is whatever was started LAST, so
+// tiles are worked on in order of how long their paths can get: tiles that show a metal or glass sphere
+// first, tiles that show only diffuse spheres next, tiles where every probe ray leaves the scene (one ray per
+// sample) last.  The order changes scheduling only: a sample's value and its slot in the sample buffer
+// depend on the image tile, not on when it is traced.
+struct TileArgs {
+    const float4* geom; const Aux* aux; int n;
+    CameraD cam; ItemGeometry ig; float tmin;
+    uint32_t tiles; uint32_t* cls; uint32_t* order;
+};
+
+// Eight probe rays per tile (corners and edge midpoints of the tile's pixel rectangle, through the lens
+// centre), one lane each; class = the largest over the probes of {0 miss, 1 lambertian, 2 metal/dielectric}.
+__global__ void __launch_bounds__(256) k_tile_class(const TileArgs a)
+{
+    const uint32_t t = blockIdx.x * 256u + threadIdx.x;
+    const uint32_t tile = t >> 3, sub = t & 7u;
+    uint32_t cls = 0;
+    if (tile < a.tiles) {
+        const int ty = (int)(tile / (uint32_t)a.ig.tiles_x), tx = (int)(tile - (uint32_t)ty * (uint32_t)a.ig.tiles_x);
+        const int r0 = ty * 8, r1 = (r0 + 7 < a.ig.owned_rows) ? r0 + 7 : a.ig.owned_rows - 1;
+        const int y0 = owned_row_to_y2(a.ig.band_rows, a.ig.band_first, a.ig.band_step, r0);
+        const int y1 = owned_row_to_y2(a.ig.band_rows, a.ig.band_first, a.ig.band_step, r1);
+        const float x_lo = (float)(tx * 8), x_hi = (float)((tx * 8 + 8 < a.ig.width) ? tx * 8 + 8 : a.ig.width);
+        const float v_hi = (float)(a.ig.height - y0), v_lo = (float)(a.ig.height - 1 - y1);
+        // probes 0..7 on a 3 x 3 grid without its centre
+        const int g = (int)(sub < 4u ? sub : sub + 1u);
+        const int gx = g % 3, gy = g / 3;
+        const float px = gx == 0 ? x_lo : gx == 1 ? 0.5f * (x_lo + x_hi) : x_hi;
+        const float py = gy == 0 ? v_lo : gy == 1 ? 0.5f * (v_lo + v_hi) : v_hi;
+        const RayD ray = get_ray(a.cam, px / (float)a.ig.width, py / (float)a.ig.height, 0.0f, 0.0f);
+        float closest = FLT_MAX; int hit = -1;
+        const float qa = dot(ray.d, ray.d);
+        for (int k = 0; k < a.n; ++k) {
+            const float4 gk = a.geom[k];
+            const V3 oc = ray.o - mk(gk.x, gk.y, gk.z);
+            const float b = dot(oc, ray.d);
+            const float desc = b * b - qa * (dot(oc, oc) - gk.w);
+            if (desc > 0.0f) {
+                const float sq = sqrtf(desc);
+                float temp = (-b - sq) / qa;
+                if (!(temp < closest && temp > a.tmin)) temp = (-b + sq) / qa;
+                if (temp < closest && temp > a.tmin) { closest = temp; hit = k; }
+            }
+        }
+        if (hit >= 0) cls = a.aux[hit].type == RT_LAMBERTIAN ? 1u : 2u;
+    }
+    for (int off = 1; off < 8; off <<= 1) { const uint32_t o = (uint32_t)__shfl_xor((int)cls, off); cls = o > cls ? o : cls; }
+    if (tile < a.tiles && sub == 0u) a.cls[tile] = cls;
+}
+
+// Stable counting sort of the tiles by class, highest class first (one block).
+__global__ void __launch_bounds__(1024) k_tile_order(const TileArgs a)
+{
+    __shared__ uint32_t s_count[3];
+    __shared__ uint32_t s_wave[16][3];
+    __shared__ uint32_t s_run[3];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    if (threadIdx.x < 3) s_count[threadIdx.x] = 0;
+    __syncthreads();
+    uint32_t mine[3] = { 0, 0, 0 };
+    for (uint32_t i = threadIdx.x; i < a.tiles; i += 1024u) mine[a.cls[i]] += 1u;
+    for (int c = 0; c < 3; ++c) if (mine[c]) atomicAdd(&s_count[c], mine[c]);
+    __syncthreads();
+    if (threadIdx.x == 0) { s_run[2] = 0; s_run[1] = s_count[2]; s_run[0] = s_count[2] + s_count[1]; }
+    __syncthreads();
+    for (uint32_t base = 0; base < a.tiles; base += 1024u) {
+        const uint32_t i = base + threadIdx.x;
+        const uint32_t c = i < a.tiles ? a.cls[i] : 3u;
+        uint32_t rank = 0;
+        for (uint32_t k = 0; k < 3; ++k) {
+            const unsigned long long m = __ballot(c == k);
+            if (c == k) rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
+            if (lane == 0) s_wave[wave][k] = (uint32_t)__popcll(m);
+        }
+        __syncthreads();
+        if (c < 3u) {
+            uint32_t before = s_run[c];
+            for (int w = 0; w < wave; ++w) before += s_wave[w][c];
+            a.order[before + rank] = i;
+        }
+        __syncthreads();
+        if (threadIdx.x < 3) { uint32_t tot = 0; for (int w = 0; w < 16; ++w) tot += s_wave[w][threadIdx.x]; s_run[threadIdx.x] += tot; }
+        __syncthreads();
+    }
 }
 
 template <bool kLds, bool kPlane, bool kRecLds = false>
@@ -485,15 +639,22 @@ __global__ void __launch_bounds__(kTraceBlock) k_trace(const TraceArgs a)
     bool active = false;
     uint32_t rays = 0, misses = 0;
     uint32_t pool_next = 0, pool_end = 0, pool_base = 0;      // wave-uniform
-    float* staged = a.staging + ((size_t)blockIdx.x * (kTraceBlock / 64) + wave) * (8 * kChunkItems);
+    float* staged = a.staging + ((size_t)blockIdx.x * (kTraceBlock / 64) + wave) * (kStagingRows * kChunkItems);
     bool exhausted = false;                    // wave-uniform
     const float fnx = (float)a.width, fny = (float)a.height;
     SecTimer T; T.start();
     ItemGeometry ig; ig.width = a.width; ig.height = a.height; ig.band_rows = a.band_rows; ig.band_first = a.band_first; ig.band_step = a.band_step;
-    ig.owned_rows = a.owned_rows; ig.tiles_x = a.tiles_x; ig.Q = a.Q; ig.s_begin = a.s_begin; ig.s_count = a.s_count;
+    ig.owned_rows = a.owned_rows; ig.tiles_x = a.tiles_x; ig.Q = a.Q; ig.s_begin = a.s_begin; ig.s_count = a.s_count; ig.tile_order = a.tile_order;
     SweepScene sw; sw.frec = a.frec; sw.prec = a.prec; sw.plane_s0 = a.plane_s0; sw.plane_rmin = a.plane_rmin; sw.geom = a.geom; sw.n = a.n; sw.n_pad = a.n_pad;
 
+#ifdef RT_SECTION_TIMERS
+    const unsigned long long t_enter = __builtin_amdgcn_s_memrealtime(); unsigned long long t_dry = 0, trips_dry = 0, sparse_trips = 0, sparse_ticks = 0, t_trip = 0; bool was_sparse = false;
+#endif
     for (;;) {
+#ifdef RT_SECTION_TIMERS
+        if (exhausted) { if (t_dry == 0) t_dry = __builtin_amdgcn_s_memrealtime(); ++trips_dry; }
+        { const unsigned long long now = __builtin_amdgcn_s_memrealtime(); if (was_sparse) { ++sparse_trips; sparse_ticks += now - t_trip; } t_trip = now; was_sparse = false; }
+#endif
         // ---------------------------------------------------------------- hand out new items
         unsigned long long need = __ballot(!active);
         while (need != 0ull && !(exhausted && pool_next == pool_end)) {
@@ -508,14 +669,15 @@ __global__ void __launch_bounds__(kTraceBlock) k_trace(const TraceArgs a)
                 // rows in HBM; handing an item to a lane later is then eight loads.  (Generating on demand
                 // ran this code on every trip of the main loop for the third of the lanes that had finished.)
                 for (uint32_t it = g + (uint32_t)lane; it < pool_end; it += 64u) {
-                    uint32_t gp = 0xffffffffu, gs = 0u; int i = 0, j = 0;
+                    uint32_t gp = 0xffffffffu, gs = 0u, gstore = 0u; int i = 0, j = 0;
                     RayD gr; gr.o = mk(0, 0, 0); gr.d = mk(0, 0, 0);
-                    if (decode_item(ig, it, gp, gs, i, j)) gr = camera_ray(a.cam, gp, gs, i, j, fnx, fny, a.k0, a.k1);
+                    if (decode_item(ig, it, gp, gs, i, j, gstore)) gr = camera_ray(a.cam, gp, gs, i, j, fnx, fny, a.k0, a.k1);
                     else gp = 0xffffffffu;
                     const uint32_t slot = it - g;
                     staged[0 * kChunkItems + slot] = gr.o.x; staged[1 * kChunkItems + slot] = gr.o.y; staged[2 * kChunkItems + slot] = gr.o.z;
                     staged[3 * kChunkItems + slot] = gr.d.x; staged[4 * kChunkItems + slot] = gr.d.y; staged[5 * kChunkItems + slot] = gr.d.z;
                     staged[6 * kChunkItems + slot] = __uint_as_float(gp); staged[7 * kChunkItems + slot] = __uint_as_float(gs);
+                    staged[8 * kChunkItems + slot] = __uint_as_float(gstore);
                 }
                 // the rows are read back by other lanes of this wave: drain the stores first
                 __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
@@ -525,14 +687,14 @@ __global__ void __launch_bounds__(kTraceBlock) k_trace(const TraceArgs a)
             const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(need >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)need, 0u));
             const uint32_t want = (uint32_t)__popcll(need);
             if (!active && rank < avail) {
-                item = pool_next + rank;
-                const uint32_t slot = item - pool_base;
+                const uint32_t slot = pool_next + rank - pool_base;
                 // device-scope loads: the staging rows are rewritten for every chunk, so a stale L1 line
                 // from the previous chunk must not be served
                 const uint32_t gp = __float_as_uint(staged_load(staged + 6 * kChunkItems + slot));
                 if (gp != 0xffffffffu) {            // 0xffffffff marks a padding pixel of an edge tile
                     pix = gp;
                     smp = __float_as_uint(staged_load(staged + 7 * kChunkItems + slot));
+                    item = __float_as_uint(staged_load(staged + 8 * kChunkItems + slot));      // where the sample is stored
                     ray.o = mk(staged_load(staged + 0 * kChunkItems + slot), staged_load(staged + 1 * kChunkItems + slot), staged_load(staged + 2 * kChunkItems + slot));
                     ray.d = mk(staged_load(staged + 3 * kChunkItems + slot), staged_load(staged + 4 * kChunkItems + slot), staged_load(staged + 5 * kChunkItems + slot));
                     depth = 0;
@@ -550,9 +712,25 @@ __global__ void __launch_bounds__(kTraceBlock) k_trace(const TraceArgs a)
             continue;
         }
 
+        // A path of L bounces needs L trips of its wave, and with six waves taking turns on a SIMD a trip lasts
+        // six times its issue time: a 50-bounce path started late keeps the whole launch waiting.  Waves that
+        // hold a deep path are therefore given issue priority over their neighbours (same total work, the long
+        // chains just finish sooner).
+        {
+            const int deepest = __any(active && depth >= 32) ? 3 : __any(active && depth >= 16) ? 2 : __any(active && depth >= 8) ? 1 : 0;
+            if (deepest == 3) __builtin_amdgcn_s_setprio(3);
+            else if (deepest == 2) __builtin_amdgcn_s_setprio(2);
+            else if (deepest == 1) __builtin_amdgcn_s_setprio(1);
+            else __builtin_amdgcn_s_setprio(0);
+        }
+        float closest = FLT_MAX; int hit = -1;
+        const unsigned long long live = __ballot(active);
+#ifdef RT_SECTION_TIMERS
+        was_sparse = __popcll(live) <= kFewPaths && live != 0ull;
+#endif
+        if (__popcll(live) <= kFewPaths) closest_hit_few<kLds>(ray, a.tmin, sw, s_geom, live, lane, closest, hit);
+        else if (active) closest_hit<kLds, kPlane, kRecLds>(ray, a.tmin, sw, s_geom, s_prec, mask_words, closest, hit, T);
         if (active) {
-            float closest = FLT_MAX; int hit = -1;
-            closest_hit<kLds, kPlane, kRecLds>(ray, a.tmin, sw, s_geom, s_prec, mask_words, closest, hit, T);
             T.mark(4);
             ++rays; misses += hit < 0 ? 1u : 0u;
             // ------------------------------------------------------------ shade (main.cpp:13-39)
@@ -567,6 +745,12 @@ __global__ void __launch_bounds__(kTraceBlock) k_trace(const TraceArgs a)
         }
     }
     T.flush(lane);
+#ifdef RT_SECTION_TIMERS
+    {
+        const uint32_t w = blockIdx.x * (kTraceBlock / 64) + wave;
+        if (lane == 0 && w < 8192u) { g_wave_times[0][w] = t_enter; const unsigned long long t_exit = __builtin_amdgcn_s_memrealtime(); g_wave_times[1][w] = t_dry ? t_dry : t_exit; g_wave_times[2][w] = t_exit; g_wave_times[3][w] = trips_dry; g_wave_times[4][w] = sparse_trips; g_wave_times[5][w] = sparse_ticks; }
+    }
+#endif
     // one atomic per wave
     for (int off = 32; off > 0; off >>= 1) { rays += __shfl_down(rays, off); misses += __shfl_down(misses, off); }
     if (lane == 0 && rays) { atomicAdd(a.ray_counter, (unsigned long long)rays); atomicAdd(a.ray_counter + 1, (unsigned long long)misses); }
@@ -627,7 +811,8 @@ __global__ void __launch_bounds__(256) k_wf_init(const WfArgs a)
     if (s == 0) { *a.work_counter = first; }
     if (s >= first) return;
     uint32_t pix = 0, smp = 0; int i = 0, j = 0;
-    const bool ok = decode_item(a.ig, s, pix, smp, i, j);
+    uint32_t store = 0;
+    const bool ok = decode_item(a.ig, s, pix, smp, i, j, store);
     // every slot starts live; a padding pixel becomes a ray that is retired (and replaced) by the first shade pass
     RayD r; r.o = mk(0, 0, 0); r.d = mk(0, 0, 0);
     if (ok) r = camera_ray(a.cam, pix, smp, i, j, (float)a.ig.width, (float)a.ig.height, a.k0, a.k1);
@@ -707,9 +892,9 @@ __global__ void __launch_bounds__(256) k_wf_shade(const WfArgs a)
         base = __builtin_amdgcn_readfirstlane(base);
         if (need) {
             const uint32_t it = base + __builtin_amdgcn_mbcnt_hi((uint32_t)(want >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)want, 0u));
-            int i = 0, j = 0;
+            int i = 0, j = 0; uint32_t store_unused = 0;
             if (it >= a.total_items) { need = false; }
-            else if (decode_item(a.ig, it, pix_out, smp_out, i, j)) {
+            else if (decode_item(a.ig, it, pix_out, smp_out, i, j, store_unused)) {
                 const RayD r = camera_ray(a.cam, pix_out, smp_out, i, j, (float)a.ig.width, (float)a.ig.height, a.k0, a.k1);
                 ray_o = r.o; ray_d = r.d; depth_out = 0; item_out = it; live = true; need = false; fresh = true;
             }
@@ -933,6 +1118,8 @@ struct rt_context {
     unsigned int* d_work = nullptr;
     uint16_t* d_stacks = nullptr; size_t stacks_lanes = 0;
     float* d_staging = nullptr;
+    uint32_t* d_tile_cls = nullptr; uint32_t* d_tile_order = nullptr; size_t tile_cap = 0;   // work order of the tiles of the current call
+    bool tile_ordering = true;
     // wavefront mode pool
     uint32_t wf_P = 0; float* wf_ray = nullptr; uint32_t* wf_pixsmp = nullptr; int* wf_depth = nullptr; float* wf_hit_t = nullptr; int* wf_hit_idx = nullptr;
     uint16_t* wf_stacks = nullptr; uint32_t* wf_q[2] = { nullptr, nullptr }; uint32_t* wf_n = nullptr;
@@ -941,6 +1128,7 @@ struct rt_context {
     bool have_camera = false; CameraD cam{};
     unsigned long long* d_rays = nullptr;      // [0] closest-hit queries, [1] those that hit nothing
     uint64_t last_samples = 0;                // primary rays of the last render (owned pixels x spp)
+    float* d_out_rgb = nullptr; int32_t* d_out_irgb = nullptr; size_t out_rgb_bytes = 0, out_irgb_bytes = 0;   // device side of rt_render's host outputs (grow-only)
     void* d_ppm_scratch = nullptr; size_t ppm_scratch_bytes = 0;    // per-block lengths and offsets of the PPM encoder
     hipEvent_t ev0 = nullptr, ev1 = nullptr; hipStream_t last_stream = nullptr; bool pending = false;
 };
@@ -993,6 +1181,10 @@ extern "C" int rt_debug_section_ticks(unsigned long long* out8, int reset)
     if (reset) { unsigned long long z[8] = { 0 }; if (hipMemcpyToSymbol(HIP_SYMBOL(g_section_ticks), z, sizeof z) != hipSuccess) return -3; }
     return 0;
 }
+extern "C" int rt_debug_wave_times(unsigned long long* out_4x8192)
+{
+    return hipMemcpyFromSymbol(out_4x8192, HIP_SYMBOL(g_wave_times), 6 * 8192 * sizeof(unsigned long long)) == hipSuccess ? 0 : -3;
+}
 #endif
 
 extern "C" {
@@ -1020,6 +1212,8 @@ int rt_create(int device_ordinal, rt_context** out)
     // RT_AMD_FILTER=disc selects the full-discriminant filter instead of the plane filter (A/B runs).
     { const char* f = getenv("RT_AMD_FILTER"); ctx->plane_filter = !(f && strcmp(f, "disc") == 0); }
     { const char* f = getenv("RT_AMD_RECORDS"); ctx->records_in_lds = (f && strcmp(f, "lds") == 0); }
+    // RT_AMD_TILE_ORDER=image works through the tiles in image order instead of longest-paths-first (A/B runs).
+    { const char* f = getenv("RT_AMD_TILE_ORDER"); ctx->tile_ordering = !(f && strcmp(f, "image") == 0); }
     hipError_t e = hipSetDevice(device_ordinal);
     if (e == hipSuccess) e = hipMalloc(&ctx->d_rays, 2 * sizeof(unsigned long long));
     if (e == hipSuccess) e = hipMalloc(&ctx->d_work, sizeof(unsigned int));
@@ -1036,8 +1230,8 @@ void rt_destroy(rt_context* ctx)
     if (!ctx) return;
     (void)hipSetDevice(ctx->device);
     if (ctx->pending) (void)hipStreamSynchronize(ctx->last_stream);
-    (void)hipFree(ctx->d_geom); (void)hipFree(ctx->d_mat); (void)hipFree(ctx->d_aux); (void)hipFree(ctx->d_rays); (void)hipFree(ctx->d_ppm_scratch);
-    (void)hipFree(ctx->d_frec); (void)hipFree(ctx->d_prec); (void)hipFree(ctx->d_samples); (void)hipFree(ctx->d_accum); (void)hipFree(ctx->d_work); (void)hipFree(ctx->d_stacks); (void)hipFree(ctx->d_staging);
+    (void)hipFree(ctx->d_geom); (void)hipFree(ctx->d_mat); (void)hipFree(ctx->d_aux); (void)hipFree(ctx->d_rays); (void)hipFree(ctx->d_ppm_scratch); (void)hipFree(ctx->d_out_rgb); (void)hipFree(ctx->d_out_irgb);
+    (void)hipFree(ctx->d_frec); (void)hipFree(ctx->d_prec); (void)hipFree(ctx->d_samples); (void)hipFree(ctx->d_accum); (void)hipFree(ctx->d_work); (void)hipFree(ctx->d_stacks); (void)hipFree(ctx->d_staging); (void)hipFree(ctx->d_tile_cls); (void)hipFree(ctx->d_tile_order);
     (void)hipFree(ctx->wf_ray); (void)hipFree(ctx->wf_pixsmp); (void)hipFree(ctx->wf_depth); (void)hipFree(ctx->wf_hit_t); (void)hipFree(ctx->wf_hit_idx);
     (void)hipFree(ctx->wf_stacks); (void)hipFree(ctx->wf_q[0]); (void)hipFree(ctx->wf_q[1]); (void)hipFree(ctx->wf_n);
     if (ctx->ev0) (void)hipEventDestroy(ctx->ev0);
@@ -1194,8 +1388,27 @@ int rt_render_device(rt_context* ctx, const rt_params* p, float* d_rgb_mean, int
             (void)hipFree(ctx->d_stacks); ctx->d_stacks = nullptr; ctx->stacks_lanes = 0;
             (void)hipFree(ctx->d_staging); ctx->d_staging = nullptr;
             HIP_TRY(ctx, hipMalloc(&ctx->d_stacks, lanes * RT_MAX_DEPTH * sizeof(uint16_t)));
-            HIP_TRY(ctx, hipMalloc(&ctx->d_staging, (lanes / 64) * 8 * kChunkItems * sizeof(float)));
+            HIP_TRY(ctx, hipMalloc(&ctx->d_staging, (lanes / 64) * kStagingRows * kChunkItems * sizeof(float)));
             ctx->stacks_lanes = lanes;
+        }
+        const uint32_t n_tiles = (uint32_t)(Q / 64);
+        const bool ordered = ctx->tile_ordering && p->mode == RT_MODE_MEGAKERNEL;
+        if (ordered) {
+            if (ctx->tile_cap < n_tiles) {
+                HIP_TRY(ctx, hipStreamSynchronize(st));
+                (void)hipFree(ctx->d_tile_cls); (void)hipFree(ctx->d_tile_order); ctx->d_tile_cls = ctx->d_tile_order = nullptr; ctx->tile_cap = 0;
+                HIP_TRY(ctx, hipMalloc(&ctx->d_tile_cls, (size_t)n_tiles * sizeof(uint32_t)));
+                HIP_TRY(ctx, hipMalloc(&ctx->d_tile_order, (size_t)n_tiles * sizeof(uint32_t)));
+                ctx->tile_cap = n_tiles;
+            }
+            TileArgs t{};
+            t.geom = ctx->d_geom; t.aux = ctx->d_aux; t.n = ctx->n; t.cam = ctx->cam; t.tmin = p->tmin;
+            t.ig.width = p->width; t.ig.height = p->height; t.ig.band_rows = p->band_rows; t.ig.band_first = p->band_first; t.ig.band_step = p->band_step;
+            t.ig.owned_rows = owned; t.ig.tiles_x = tiles_x; t.ig.Q = (uint32_t)Q; t.ig.s_begin = 0; t.ig.s_count = 1; t.ig.tile_order = nullptr;
+            t.tiles = n_tiles; t.cls = ctx->d_tile_cls; t.order = ctx->d_tile_order;
+            hipLaunchKernelGGL(k_tile_class, dim3((n_tiles * 8u + 255u) / 256u), dim3(256), 0, st, t);
+            hipLaunchKernelGGL(k_tile_order, dim3(1), dim3(1024), 0, st, t);
+            HIP_TRY(ctx, hipGetLastError());
         }
         for (int bi = 0, s0 = 0; bi < batches; ++bi, s0 += s_per) {
             const int sc = (p->spp - s0 < s_per) ? p->spp - s0 : s_per;
@@ -1223,7 +1436,7 @@ int rt_render_device(rt_context* ctx, const rt_params* p, float* d_rgb_mean, int
                 w.sw.frec = ctx->d_frec; w.sw.prec = ctx->d_prec; w.sw.plane_s0 = ctx->plane_s0; w.sw.plane_rmin = ctx->plane_rmin; w.sw.geom = ctx->d_geom; w.sw.n = ctx->n; w.sw.n_pad = ctx->n_pad;
                 w.mat = ctx->d_mat; w.aux = ctx->d_aux; w.cam = ctx->cam;
                 w.ig.width = p->width; w.ig.height = p->height; w.ig.band_rows = p->band_rows; w.ig.band_first = p->band_first; w.ig.band_step = p->band_step;
-                w.ig.owned_rows = owned; w.ig.tiles_x = tiles_x; w.ig.Q = (uint32_t)Q; w.ig.s_begin = s0; w.ig.s_count = sc;
+                w.ig.owned_rows = owned; w.ig.tiles_x = tiles_x; w.ig.Q = (uint32_t)Q; w.ig.s_begin = s0; w.ig.s_count = sc; w.ig.tile_order = nullptr;
                 w.max_depth = p->max_depth; w.tmin = p->tmin; w.k0 = (uint32_t)p->seed; w.k1 = (uint32_t)(p->seed >> 32);
                 w.total_items = total; w.P = ctx->wf_P;
                 w.ray = ctx->wf_ray; w.pixsmp = ctx->wf_pixsmp; w.depth = ctx->wf_depth; w.hit_t = ctx->wf_hit_t; w.hit_idx = ctx->wf_hit_idx; w.stacks = ctx->wf_stacks;
@@ -1273,6 +1486,7 @@ int rt_render_device(rt_context* ctx, const rt_params* p, float* d_rgb_mean, int
             a.tiles_x = tiles_x; a.Q = (uint32_t)Q; a.s_begin = s0; a.s_count = sc; a.total_items = (uint32_t)(Q * sc);
             a.samples = ctx->d_samples; a.ray_counter = ctx->d_rays; a.work_counter = ctx->d_work;
             a.stacks = ctx->d_stacks; a.stack_stride = (uint32_t)ctx->stacks_lanes; a.staging = ctx->d_staging;
+            a.tile_order = ordered ? ctx->d_tile_order : nullptr;
             HIP_TRY(ctx, hipMemsetAsync(ctx->d_work, 0, sizeof(unsigned int), st));
             // small jobs take smaller chunks so that every resident wave gets several (tail balance)
             const uint64_t resident_waves = (uint64_t)ctx->num_cu * bpc * (kTraceBlock / 64);
@@ -1341,14 +1555,28 @@ int rt_render(rt_context* ctx, const rt_params* p, float* h_rgb_mean, int32_t* h
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     const size_t npx = (size_t)rt_owned_pixels(p);
     float* d_rgb = nullptr; int32_t* d_i = nullptr;
-    int rc = RT_OK;
-    if (h_rgb_mean && npx) { hipError_t e = hipMalloc(&d_rgb, npx * 3 * sizeof(float)); if (e != hipSuccess) return fail(ctx, RT_ERR_HIP, "rt_render: hipMalloc: %s", hipGetErrorString(e)); }
-    if (h_irgb && npx) { hipError_t e = hipMalloc(&d_i, npx * 3 * sizeof(int32_t)); if (e != hipSuccess) { (void)hipFree(d_rgb); return fail(ctx, RT_ERR_HIP, "rt_render: hipMalloc: %s", hipGetErrorString(e)); } }
-    rc = rt_render_device(ctx, p, d_rgb, d_i, nullptr);
+    // The device side of the host outputs is kept in the context between calls (band-by-band callers make
+    // many small calls; an allocation and a free per call cost more than the band's kernels).
+    if (h_rgb_mean && npx) {
+        const size_t need = npx * 3 * sizeof(float);
+        if (ctx->out_rgb_bytes < need) {
+            (void)hipFree(ctx->d_out_rgb); ctx->d_out_rgb = nullptr; ctx->out_rgb_bytes = 0;
+            HIP_TRY(ctx, hipMalloc(&ctx->d_out_rgb, need)); ctx->out_rgb_bytes = need;
+        }
+        d_rgb = ctx->d_out_rgb;
+    }
+    if (h_irgb && npx) {
+        const size_t need = npx * 3 * sizeof(int32_t);
+        if (ctx->out_irgb_bytes < need) {
+            (void)hipFree(ctx->d_out_irgb); ctx->d_out_irgb = nullptr; ctx->out_irgb_bytes = 0;
+            HIP_TRY(ctx, hipMalloc(&ctx->d_out_irgb, need)); ctx->out_irgb_bytes = need;
+        }
+        d_i = ctx->d_out_irgb;
+    }
+    int rc = rt_render_device(ctx, p, d_rgb, d_i, nullptr);
     if (rc == RT_OK) rc = rt_render_stats(ctx, rays, kernel_ms);
     if (rc == RT_OK && d_rgb) { hipError_t e = hipMemcpy(h_rgb_mean, d_rgb, npx * 3 * sizeof(float), hipMemcpyDeviceToHost); if (e != hipSuccess) rc = fail(ctx, RT_ERR_HIP, "rt_render: copy back: %s", hipGetErrorString(e)); }
     if (rc == RT_OK && d_i) { hipError_t e = hipMemcpy(h_irgb, d_i, npx * 3 * sizeof(int32_t), hipMemcpyDeviceToHost); if (e != hipSuccess) rc = fail(ctx, RT_ERR_HIP, "rt_render: copy back: %s", hipGetErrorString(e)); }
-    (void)hipFree(d_rgb); (void)hipFree(d_i);
     return rc;
 }
 

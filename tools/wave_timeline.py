@@ -1,0 +1,40 @@
+#!/usr/bin/env python3
+"""When do the persistent waves of k_trace stop?  Diagnostic build (make -C raytracing_amd/csrc prof): per wave the
+s_memrealtime stamps at entry, at the moment it first found the work counter dry, and at exit (100 MHz ticks)."""
+import ctypes as C
+import os
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+os.environ["RT_AMD_LIB"] = os.path.join(ROOT, "tools", "librt_amd_prof.so")
+sys.path.insert(0, ROOT)
+import raytracing_amd as R
+
+spp = int(sys.argv[1]) if len(sys.argv) > 1 else 10
+depth = int(sys.argv[2]) if len(sys.argv) > 2 else 50
+rt = R.Renderer(0)
+rt.upload_scene(R.final_scene_table())
+rt.set_camera(R.final_camera(1200, 800))
+L = R.load_library()
+buf = np.zeros((6, 8192), dtype=np.uint64)
+for rep in range(2):
+    rgb, irgb, rays, ms = rt.render(rt.params(1200, 800, spp, seed=0, max_depth=depth))
+L.rt_debug_wave_times(buf.ctypes.data_as(C.POINTER(C.c_ulonglong)))
+live = buf[2] > 0
+t0 = buf[0][live].min()
+enter, dry, exit_, trips = [(buf[k][live].astype(np.int64) - int(t0)) / 100.0 for k in range(3)] + [buf[3][live]]   # microseconds
+print(f"spp {spp} depth {depth}: {rays} rays, kernel {ms:.3f} ms, {live.sum()} waves")
+print("entry   us: min %.0f  median %.0f  max %.0f" % (enter.min(), np.median(enter), enter.max()))
+print("dry     us: min %.0f  median %.0f  max %.0f" % (dry.min(), np.median(dry), dry.max()))
+print("exit    us: min %.0f  p10 %.0f  median %.0f  p90 %.0f  p99 %.0f  max %.0f" % (exit_.min(), *np.percentile(exit_, [10, 50, 90, 99]), exit_.max()))
+d = exit_ - dry
+print("drain   us: median %.0f  p90 %.0f  p99 %.0f  max %.0f;  trips after dry: median %.0f p90 %.0f max %.0f" %
+      (np.median(d), *np.percentile(d, [90, 99]), d.max(), np.median(trips), np.percentile(trips, 90), trips.max()))
+edges = np.linspace(0, exit_.max(), 21)
+alive = [(exit_ > e).sum() for e in edges]
+print("waves still running at t (us):", ", ".join(f"{e:.0f}:{a}" for e, a in zip(edges, alive)))
+st, sk = buf[4][live].astype(np.float64), buf[5][live].astype(np.float64) / 100.0
+print("sparse trips: total %d, mean %.2f us per trip; waves with > 20 sparse trips: %d, their mean trip %.2f us" %
+      (st.sum(), sk.sum() / max(st.sum(), 1), (st > 20).sum(), sk[st > 20].sum() / max(st[st > 20].sum(), 1)))
