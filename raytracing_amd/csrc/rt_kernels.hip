@@ -1120,6 +1120,9 @@ struct rt_context {
     float* d_staging = nullptr;
     uint32_t* d_tile_cls = nullptr; uint32_t* d_tile_order = nullptr; size_t tile_cap = 0;   // work order of the tiles of the current call
     bool tile_ordering = true;
+    // the order depends on scene, camera and the rows rendered only: it is kept for repeated calls (new seeds, more samples)
+    struct TileKey { uint64_t scene_version, camera_version; int32_t width, height, band_rows, band_first, band_step; float tmin; } tile_key{};
+    bool tile_key_valid = false; uint64_t scene_version = 0, camera_version = 0;
     // wavefront mode pool
     uint32_t wf_P = 0; float* wf_ray = nullptr; uint32_t* wf_pixsmp = nullptr; int* wf_depth = nullptr; float* wf_hit_t = nullptr; int* wf_hit_idx = nullptr;
     uint16_t* wf_stacks = nullptr; uint32_t* wf_q[2] = { nullptr, nullptr }; uint32_t* wf_n = nullptr;
@@ -1302,7 +1305,7 @@ int rt_upload_scene(rt_context* ctx, int n, const float* cx, const float* cy, co
     HIP_TRY(ctx, hipMemcpy(ctx->d_geom, geom.data(), sizeof(float4) * n, hipMemcpyHostToDevice));
     HIP_TRY(ctx, hipMemcpy(ctx->d_mat, mat.data(), sizeof(float4) * n, hipMemcpyHostToDevice));
     HIP_TRY(ctx, hipMemcpy(ctx->d_aux, aux.data(), sizeof(Aux) * n, hipMemcpyHostToDevice));
-    ctx->n = n;
+    ctx->n = n; ++ctx->scene_version;
     return RT_OK;
 }
 
@@ -1311,7 +1314,7 @@ int rt_set_camera(rt_context* ctx, const rt_camera_pod* cam)
     if (!ctx) return fail(nullptr, RT_ERR_INVALID, "rt_set_camera: null context");
     if (!cam) return fail(ctx, RT_ERR_INVALID, "rt_set_camera: null camera");
     ctx->cam = to_device(*cam);
-    ctx->have_camera = true;
+    ctx->have_camera = true; ++ctx->camera_version;
     return RT_OK;
 }
 
@@ -1396,19 +1399,24 @@ int rt_render_device(rt_context* ctx, const rt_params* p, float* d_rgb_mean, int
         if (ordered) {
             if (ctx->tile_cap < n_tiles) {
                 HIP_TRY(ctx, hipStreamSynchronize(st));
-                (void)hipFree(ctx->d_tile_cls); (void)hipFree(ctx->d_tile_order); ctx->d_tile_cls = ctx->d_tile_order = nullptr; ctx->tile_cap = 0;
+                (void)hipFree(ctx->d_tile_cls); (void)hipFree(ctx->d_tile_order); ctx->d_tile_cls = ctx->d_tile_order = nullptr; ctx->tile_cap = 0; ctx->tile_key_valid = false;
                 HIP_TRY(ctx, hipMalloc(&ctx->d_tile_cls, (size_t)n_tiles * sizeof(uint32_t)));
                 HIP_TRY(ctx, hipMalloc(&ctx->d_tile_order, (size_t)n_tiles * sizeof(uint32_t)));
                 ctx->tile_cap = n_tiles;
             }
+            const rt_context::TileKey key{ ctx->scene_version, ctx->camera_version, p->width, p->height, p->band_rows, p->band_first, p->band_step, p->tmin };
+            const bool cached = ctx->tile_key_valid && memcmp(&key, &ctx->tile_key, sizeof key) == 0;
             TileArgs t{};
             t.geom = ctx->d_geom; t.aux = ctx->d_aux; t.n = ctx->n; t.cam = ctx->cam; t.tmin = p->tmin;
             t.ig.width = p->width; t.ig.height = p->height; t.ig.band_rows = p->band_rows; t.ig.band_first = p->band_first; t.ig.band_step = p->band_step;
             t.ig.owned_rows = owned; t.ig.tiles_x = tiles_x; t.ig.Q = (uint32_t)Q; t.ig.s_begin = 0; t.ig.s_count = 1; t.ig.tile_order = nullptr;
             t.tiles = n_tiles; t.cls = ctx->d_tile_cls; t.order = ctx->d_tile_order;
-            hipLaunchKernelGGL(k_tile_class, dim3((n_tiles * 8u + 255u) / 256u), dim3(256), 0, st, t);
-            hipLaunchKernelGGL(k_tile_order, dim3(1), dim3(1024), 0, st, t);
-            HIP_TRY(ctx, hipGetLastError());
+            if (!cached) {
+                hipLaunchKernelGGL(k_tile_class, dim3((n_tiles * 8u + 255u) / 256u), dim3(256), 0, st, t);
+                hipLaunchKernelGGL(k_tile_order, dim3(1), dim3(1024), 0, st, t);
+                HIP_TRY(ctx, hipGetLastError());
+                ctx->tile_key = key; ctx->tile_key_valid = true;
+            }
         }
         for (int bi = 0, s0 = 0; bi < batches; ++bi, s0 += s_per) {
             const int sc = (p->spp - s0 < s_per) ? p->spp - s0 : s_per;

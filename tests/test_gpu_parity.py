@@ -395,3 +395,57 @@ def test_ppm_text_encoded_on_the_gpu_equals_the_host_formatter(rt, tmp_path):
     assert open(path, "rb").read() == R.format_ppm(d_irgb.cpu().numpy())
     with pytest.raises(R.RtError):
         rt.write_ppm_device("/nonexistent_dir/x.ppm", d_irgb.data_ptr(), 96, 64)
+
+
+def _random_scene(rng, n):
+    """Spheres with the awkward cases the reference's code accepts without complaint: negative radii (hollow
+    glass, main.cpp:107), exact duplicates (ties go to the lower index, hittablelist.cpp:21-29), overlapping and
+    nested spheres, a camera that may sit inside one, fuzz above the constructor's clamp, odd refraction indices."""
+    t = np.zeros((n, 9), dtype=np.float64)
+    t[:, 0:3] = rng.uniform(-3.0, 3.0, size=(n, 3))
+    t[:, 3] = np.exp(rng.uniform(np.log(0.02), np.log(2.5), size=n))
+    t[:, 4] = rng.integers(0, 3, size=n)
+    t[:, 5:8] = rng.uniform(0.05, 1.0, size=(n, 3))
+    for k in range(n):
+        if t[k, 4] == R.METAL:
+            t[k, 8] = min(rng.choice([0.0, 0.3, 1.0, 1.7]), 1.0)        # Metal's constructor clamps fuzz to 1 (material.h:73-83)
+        elif t[k, 4] == R.DIELECTRIC:
+            t[k, 8] = rng.choice([1.5, 0.8, 1.0, 2.4])
+            t[k, 5:8] = 1.0
+            if rng.random() < 0.4:
+                t[k, 3] = -t[k, 3]
+        if k > 0 and rng.random() < 0.15:                               # exact duplicate of an earlier sphere, other material
+            src = rng.integers(0, k)
+            t[k, 0:4] = t[src, 0:4]
+    if n > 3 and rng.random() < 0.5:
+        t[0] = [0.0, -1000.0, 0.0, 1000.0, R.LAMBERTIAN, 0.5, 0.5, 0.5, 0.0]
+    return np.asarray(t, dtype=np.float32).astype(np.float64)
+
+
+def test_random_scenes_match_oracle_in_all_modes(rt):
+    """Seeded random scenes and cameras, small images: the three kernel organisations against the CPU oracle,
+    bit for bit (image, quantised integers, ray count and the RenderStats counters)."""
+    rng = np.random.default_rng(20240607)
+    W, H, S = 40, 24, 3
+    for case, n in enumerate([1, 2, 5, 31, 32, 33, 64, 65, 200, 513, 1537, 1600]):
+        table = _random_scene(rng, n)
+        look_from = rng.uniform(-4.0, 4.0, size=3)
+        look_at = rng.uniform(-1.0, 1.0, size=3)
+        vfov = float(rng.choice([20.0, 60.0, 110.0]))
+        aperture = float(rng.choice([0.0, 0.3]))
+        ocam = O.make_camera(look_from, look_at, (0.0, 1.0, 0.0), vfov, np.float32(W) / np.float32(H), aperture, float(rng.uniform(1.0, 6.0)))
+        pod = R.CameraPod()
+        for dst, src in (("origin", "origin"), ("lower_left_corner", "llc"), ("horizontal", "horiz"), ("vertical", "vert"), ("u", "u"), ("v", "v"), ("w", "w")):
+            vec = getattr(ocam, src)
+            getattr(pod, dst)[:] = [vec.x, vec.y, vec.z]
+        pod.lens_radius = ocam.lens_radius
+        rt.upload_scene(table)
+        rt.set_camera(pod)
+        seed = 1000 + case
+        want, wq, wrays, wcount = O.render_counted(O.SceneArrays.from_table(table), ocam, W, H, S, O.usrc_philox(seed))
+        for mode in (R.MODE_MEGAKERNEL, R.MODE_WAVEFRONT, R.MODE_PIXEL):
+            rgb, irgb, rays, _ = rt.render(rt.params(W, H, S, seed=seed, mode=mode))
+            assert rays == wrays, (case, n, mode)
+            assert rt.counters() == wcount, (case, n, mode)
+            assert mismatch(rgb, want) == 0, (case, n, mode, mismatch(rgb, want))
+            assert np.array_equal(irgb, wq), (case, n, mode)
