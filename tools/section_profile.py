@@ -19,7 +19,7 @@ buf = (C.c_ulonglong * 8)()
 L.rt_debug_section_ticks(buf, 1)
 rgb, irgb, rays, ms = rt.render(rt.params(1200, 800, spp, seed=0))
 L.rt_debug_section_ticks(buf, 0)
-names = ["regenerate", "ray setup+filter", "exact pass A", "exact pass B", "-", "hit record", "scatter", "sky+store"]
+names = ["regenerate", "ray setup+filter", "exact pass A", "exact pass B", "sparse sweep", "hit record", "scatter", "sky+store"]
 order = [0, 1, 2, 3, 4, 5, 6, 7]
 tot = sum(buf[i] for i in order)
 print(f"{rays} rays, kernel {ms:.2f} ms (timers add overhead)")
