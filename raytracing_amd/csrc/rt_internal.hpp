@@ -1,0 +1,82 @@
+// Shared by the translation units of librt_amd.so: the context behind the opaque rt_context handle of
+// include/rt_amd.h, error reporting, and a scoped device buffer for the entry points that take host arrays.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <cstdarg>
+#include <cstdint>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+#include "rt_amd.h"
+#include "rt_device.hpp"
+
+using namespace rt;
+
+// aux[i] = (radius, type): read once per hit (normal = (p - c) / radius, Scatter dispatch)
+struct Aux { float radius; int type; };
+
+struct rt_context {
+    int device = -1;
+    std::string error;
+    float4* d_geom = nullptr; float4* d_mat = nullptr; Aux* d_aux = nullptr; int n = 0;
+    float4* d_frec = nullptr; float4* d_prec = nullptr; float plane_s0 = 0.0f; float plane_rmin = 1.0f; int n_pad = 0;
+    bool plane_filter = true;
+    bool records_in_lds = false;      // measurement variant, RT_AMD_RECORDS=lds
+    float* d_samples = nullptr; size_t samples_bytes = 0;      // sample buffer of the persistent megakernel
+    float* d_accum = nullptr; size_t accum_bytes = 0;          // running per-pixel sums across sample batches
+    unsigned int* d_work = nullptr;
+    uint16_t* d_stacks = nullptr; size_t stacks_lanes = 0;
+    float* d_staging = nullptr;
+    uint32_t* d_tile_cls = nullptr; uint32_t* d_tile_order = nullptr; size_t tile_cap = 0;   // work order of the tiles of the current call
+    bool tile_ordering = true;
+    // the order depends on scene, camera and the rows rendered only: it is kept for repeated calls (new seeds, more samples)
+    struct TileKey { uint64_t scene_version, camera_version; int32_t width, height, band_rows, band_first, band_step; float tmin; } tile_key{};
+    bool tile_key_valid = false; uint64_t scene_version = 0, camera_version = 0;
+    // wavefront mode pool
+    uint32_t wf_P = 0; float* wf_ray = nullptr; uint32_t* wf_pixsmp = nullptr; int* wf_depth = nullptr; float* wf_hit_t = nullptr; int* wf_hit_idx = nullptr;
+    uint16_t* wf_stacks = nullptr; uint32_t* wf_q[2] = { nullptr, nullptr }; uint32_t* wf_n = nullptr;
+    int wf_blocks_per_cu[4] = { 0, 0, 0, 0 };
+    int num_cu = 0; int trace_blocks_per_cu[5] = { 0, 0, 0, 0, 0 };
+    bool have_camera = false; CameraD cam{};
+    unsigned long long* d_rays = nullptr;      // [0] closest-hit queries, [1] those that hit nothing
+    uint64_t last_samples = 0;                // primary rays of the last render (owned pixels x spp)
+    float* d_out_rgb = nullptr; int32_t* d_out_irgb = nullptr; size_t out_rgb_bytes = 0, out_irgb_bytes = 0;   // device side of rt_render's host outputs (grow-only)
+    void* d_ppm_scratch = nullptr; size_t ppm_scratch_bytes = 0;    // per-block lengths and offsets of the PPM encoder
+    hipEvent_t ev0 = nullptr, ev1 = nullptr; hipStream_t last_stream = nullptr; bool pending = false;
+};
+
+// Records the message on the context (or, without one, in a per-thread slot read by rt_last_error(NULL)) and returns `code`.
+int fail(rt_context* ctx, int code, const char* fmt, ...) __attribute__((format(printf, 3, 4), visibility("hidden")));
+#define HIP_TRY(ctx, call) do { hipError_t e_ = (call); if (e_ != hipSuccess) return fail(ctx, RT_ERR_HIP, "%s failed: %s", #call, hipGetErrorString(e_)); } while (0)
+
+inline CameraD to_device(const rt_camera_pod& c)
+{
+    CameraD d;
+    d.origin = { c.origin[0], c.origin[1], c.origin[2] };
+    d.llc = { c.lower_left_corner[0], c.lower_left_corner[1], c.lower_left_corner[2] };
+    d.horiz = { c.horizontal[0], c.horizontal[1], c.horizontal[2] };
+    d.vert = { c.vertical[0], c.vertical[1], c.vertical[2] };
+    d.u = { c.u[0], c.u[1], c.u[2] };
+    d.v = { c.v[0], c.v[1], c.v[2] };
+    d.lens_radius = c.lens_radius;
+    return d;
+}
+
+inline bool params_ok(const rt_params* p)
+{
+    return p && p->width > 0 && p->height > 0 && p->spp > 0 && p->max_depth >= 0 && p->max_depth <= RT_MAX_DEPTH &&
+           p->band_rows > 0 && p->band_first >= 0 && p->band_step > 0 &&
+           (p->mode == RT_MODE_MEGAKERNEL || p->mode == RT_MODE_WAVEFRONT || p->mode == RT_MODE_PIXEL);
+}
+
+namespace {
+struct DevBuf {
+    void* p = nullptr;
+    ~DevBuf() { if (p) (void)hipFree(p); }
+    hipError_t up(const void* h, size_t bytes) { hipError_t e = hipMalloc(&p, bytes ? bytes : 4); if (e == hipSuccess && h && bytes) e = hipMemcpy(p, h, bytes, hipMemcpyHostToDevice); return e; }
+    hipError_t down(void* h, size_t bytes) { return hipMemcpy(h, p, bytes, hipMemcpyDeviceToHost); }
+    template <class T> T* as() { return static_cast<T*>(p); }
+};
+}
+

@@ -8,17 +8,13 @@
 #include <string>
 #include <type_traits>
 #include <vector>
-#include "rt_amd.h"
-#include "rt_device.hpp"
-
-using namespace rt;
+#include "rt_internal.hpp"
 
 // ============================================================================ device data layout
 // Scene records in HBM (built once per upload) and, for the megakernel, mirrored into LDS:
 //   geom[i] = (cx, cy, cz, r*r)       16 B  -- everything the sweep touches
 //   mat[i]  = (ar, ag, ab, param)     16 B  -- read once per hit
 //   aux[i]  = (radius, type)           8 B  -- read once per hit (normal = (p - c) / radius)
-struct Aux { float radius; int type; };
 
 struct RenderArgs {
     const float4* geom; const float4* mat; const Aux* aux; int n;
@@ -919,262 +915,15 @@ __global__ void __launch_bounds__(256) k_wf_shade(const WfArgs a)
     }
 }
 
-// ============================================================================ unit-level kernels
-__global__ void k_test_sphere_hit(int n, const float* ro, const float* rd, const float* c, const float* radius,
-                                  const float* tmin, const float* tmax, int32_t* hit, float* t, float* p, float* nrm)
-{
-    const int e = blockIdx.x * blockDim.x + threadIdx.x;
-    if (e >= n) return;
-    RayD r; r.o = mk(ro[3 * e], ro[3 * e + 1], ro[3 * e + 2]); r.d = mk(rd[3 * e], rd[3 * e + 1], rd[3 * e + 2]);
-    HitD rec; rec.t = 0; rec.p = mk(0, 0, 0); rec.n = mk(0, 0, 0);
-    const bool h = sphere_hit(r, mk(c[3 * e], c[3 * e + 1], c[3 * e + 2]), radius[e], tmin[e], tmax[e], rec);
-    hit[e] = h ? 1 : 0; t[e] = h ? rec.t : 0.0f;
-    p[3 * e] = h ? rec.p.x : 0; p[3 * e + 1] = h ? rec.p.y : 0; p[3 * e + 2] = h ? rec.p.z : 0;
-    nrm[3 * e] = h ? rec.n.x : 0; nrm[3 * e + 1] = h ? rec.n.y : 0; nrm[3 * e + 2] = h ? rec.n.z : 0;
-}
-
-__global__ void k_test_scatter(int n, const int32_t* type, const float* albedo, const float* param, const float* ro,
-                               const float* rd, const float* hp, const float* hn, const int32_t* draws, int per,
-                               int32_t* ret, float* att, float* oo, float* od, int32_t* used)
-{
-    const int e = blockIdx.x * blockDim.x + threadIdx.x;
-    if (e >= n) return;
-    RayD in; in.o = mk(ro[3 * e], ro[3 * e + 1], ro[3 * e + 2]); in.d = mk(rd[3 * e], rd[3 * e + 1], rd[3 * e + 2]);
-    ReplayUniforms U; U.draws = draws + (size_t)e * per; U.pos = 0;
-    V3 a = mk(0, 0, 0); RayD out; out.o = mk(0, 0, 0); out.d = mk(0, 0, 0);
-    const bool rv = scatter(type[e], mk(albedo[3 * e], albedo[3 * e + 1], albedo[3 * e + 2]), param[e], in,
-                            mk(hp[3 * e], hp[3 * e + 1], hp[3 * e + 2]), mk(hn[3 * e], hn[3 * e + 1], hn[3 * e + 2]), U, a, out);
-    ret[e] = rv ? 1 : 0; used[e] = U.pos;
-    att[3 * e] = a.x; att[3 * e + 1] = a.y; att[3 * e + 2] = a.z;
-    oo[3 * e] = out.o.x; oo[3 * e + 1] = out.o.y; oo[3 * e + 2] = out.o.z;
-    od[3 * e] = out.d.x; od[3 * e + 1] = out.d.y; od[3 * e + 2] = out.d.z;
-}
-
-__global__ void k_test_get_ray(int n, const CameraD cam, const float* s, const float* t, const float* disk, float* ro, float* rd)
-{
-    const int e = blockIdx.x * blockDim.x + threadIdx.x;
-    if (e >= n) return;
-    const RayD r = get_ray(cam, s[e], t[e], disk[2 * e], disk[2 * e + 1]);
-    ro[3 * e] = r.o.x; ro[3 * e + 1] = r.o.y; ro[3 * e + 2] = r.o.z;
-    rd[3 * e] = r.d.x; rd[3 * e + 1] = r.d.y; rd[3 * e + 2] = r.d.z;
-}
-
-__global__ void k_test_philox(int n, const uint32_t* ctr, uint32_t k0, uint32_t k1, uint32_t* out)
-{
-    const int e = blockIdx.x * blockDim.x + threadIdx.x;
-    if (e >= n) return;
-    const U4 w = philox4x32_10(ctr[4 * e], ctr[4 * e + 1], ctr[4 * e + 2], ctr[4 * e + 3], k0, k1);
-    out[4 * e] = w.x; out[4 * e + 1] = w.y; out[4 * e + 2] = w.z; out[4 * e + 3] = w.w;
-}
-
 // ============================================================================ host side
-// ============================================================================ output.ppm on the GPU
-// ASCII P3 text of main.cpp:95-97,143-144 ("r g b\n" per pixel) produced from the quantised image
-// without a trip through host formatting: a length pass, a scan of per-block lengths, and a write pass
-// that lays the block's text out in LDS and streams it to HBM as whole dwords.
-constexpr int kPpmBlock = 256, kPpmPxPerThread = 4, kPpmPxPerBlock = kPpmBlock * kPpmPxPerThread;
-constexpr int kPpmMaxLine = 36;        // three ints of up to 11 characters, two blanks, one newline
-
-__device__ __forceinline__ int ppm_digits(int32_t v)
-{
-    const uint32_t u = v < 0 ? 0u - (uint32_t)v : (uint32_t)v;
-    int n = 1;
-    if (u >= 10u) n = 2;
-    if (u >= 100u) n = 3;
-    if (u >= 1000u) {
-        n = 4;
-        if (u >= 10000u) n = 5;
-        if (u >= 100000u) n = 6;
-        if (u >= 1000000u) n = 7;
-        if (u >= 10000000u) n = 8;
-        if (u >= 100000000u) n = 9;
-        if (u >= 1000000000u) n = 10;
-    }
-    return n + (v < 0 ? 1 : 0);
-}
-__device__ __forceinline__ int ppm_line_length(int32_t r, int32_t g, int32_t b) { return ppm_digits(r) + ppm_digits(g) + ppm_digits(b) + 3; }
-
-// Writes v in decimal followed by `sep` at q (LDS), returns the position after it.
-__device__ __forceinline__ char* ppm_put(char* q, int32_t v, char sep)
-{
-    const int n = ppm_digits(v);
-    uint32_t u = v < 0 ? 0u - (uint32_t)v : (uint32_t)v;
-    if (v < 0) q[0] = '-';
-    for (int k = n - 1; k >= (v < 0 ? 1 : 0); --k) { q[k] = (char)('0' + u % 10u); u /= 10u; }
-    q[n] = sep;
-    return q + n + 1;
-}
-
-struct PpmArgs {
-    const int32_t* irgb; uint32_t pixels;
-    uint32_t* block_len; unsigned long long* block_off;    // [blocks], [blocks + 1]
-    uint32_t blocks;
-    char* text; int header_len; char header[40];
-};
-
-__device__ __forceinline__ uint32_t ppm_block_scan(uint32_t mine, uint32_t* s_wave, uint32_t& block_total)
-{
-    // exclusive scan of `mine` over the 256 threads of the block
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    uint32_t incl = mine;
-    for (int off = 1; off < 64; off <<= 1) { const uint32_t t = __shfl_up(incl, off); if (lane >= off) incl += t; }
-    if (lane == 63) s_wave[wave] = incl;
-    __syncthreads();
-    uint32_t base = 0, total = 0;
-    for (int w = 0; w < kPpmBlock / 64; ++w) { const uint32_t t = s_wave[w]; if (w < wave) base += t; total += t; }
-    block_total = total;
-    return base + incl - mine;
-}
-
-__global__ void __launch_bounds__(kPpmBlock) k_ppm_len(const PpmArgs a)
-{
-    __shared__ uint32_t s_wave[kPpmBlock / 64];
-    const uint32_t first = (blockIdx.x * (uint32_t)kPpmBlock + threadIdx.x) * (uint32_t)kPpmPxPerThread;
-    uint32_t mine = 0;
-    for (int k = 0; k < kPpmPxPerThread; ++k) {
-        const uint32_t px = first + (uint32_t)k;
-        if (px < a.pixels) mine += (uint32_t)ppm_line_length(a.irgb[3 * (size_t)px], a.irgb[3 * (size_t)px + 1], a.irgb[3 * (size_t)px + 2]);
-    }
-    uint32_t total = 0;
-    (void)ppm_block_scan(mine, s_wave, total);
-    if (threadIdx.x == 0) a.block_len[blockIdx.x] = total;
-}
-
-// One block: exclusive scan of the per-block lengths into 64-bit offsets; block_off[blocks] = text bytes after the header.
-__global__ void __launch_bounds__(1024) k_ppm_scan(const PpmArgs a)
-{
-    __shared__ unsigned long long s_wave[16];
-    __shared__ unsigned long long s_carry;
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    if (threadIdx.x == 0) s_carry = 0ull;
-    __syncthreads();
-    for (uint32_t base = 0; base < a.blocks; base += 1024u) {
-        const uint32_t i = base + threadIdx.x;
-        const unsigned long long mine = i < a.blocks ? (unsigned long long)a.block_len[i] : 0ull;
-        unsigned long long incl = mine;
-        for (int off = 1; off < 64; off <<= 1) { const unsigned long long t = __shfl_up(incl, off); if (lane >= off) incl += t; }
-        if (lane == 63) s_wave[wave] = incl;
-        __syncthreads();
-        unsigned long long before = s_carry, total = 0ull;
-        for (int w = 0; w < 16; ++w) { const unsigned long long t = s_wave[w]; if (w < wave) before += t; total += t; }
-        if (i < a.blocks) a.block_off[i] = before + incl - mine;
-        __syncthreads();
-        if (threadIdx.x == 0) s_carry += total;
-        __syncthreads();
-    }
-    if (threadIdx.x == 0) a.block_off[a.blocks] = s_carry;
-}
-
-__global__ void __launch_bounds__(kPpmBlock) k_ppm_write(const PpmArgs a)
-{
-    // text of the block, placed so that LDS byte k lands on HBM byte (dst rounded down to 4) + k
-    __shared__ __attribute__((aligned(16))) char s_text[kPpmPxPerBlock * kPpmMaxLine + 8];
-    __shared__ uint32_t s_wave[kPpmBlock / 64];
-    const uint32_t first = (blockIdx.x * (uint32_t)kPpmBlock + threadIdx.x) * (uint32_t)kPpmPxPerThread;
-    int32_t v[kPpmPxPerThread][3];
-    uint32_t mine = 0;
-    for (int k = 0; k < kPpmPxPerThread; ++k) {
-        const uint32_t px = first + (uint32_t)k;
-        if (px < a.pixels) {
-            v[k][0] = a.irgb[3 * (size_t)px]; v[k][1] = a.irgb[3 * (size_t)px + 1]; v[k][2] = a.irgb[3 * (size_t)px + 2];
-            mine += (uint32_t)ppm_line_length(v[k][0], v[k][1], v[k][2]);
-        }
-    }
-    uint32_t total = 0;
-    const uint32_t at = ppm_block_scan(mine, s_wave, total);
-    char* dst = a.text + a.header_len + a.block_off[blockIdx.x];
-    const uint32_t shift = (uint32_t)(reinterpret_cast<uintptr_t>(dst) & 3u);
-    char* q = s_text + shift + at;
-    for (int k = 0; k < kPpmPxPerThread; ++k) {
-        if (first + (uint32_t)k < a.pixels) { q = ppm_put(q, v[k][0], ' '); q = ppm_put(q, v[k][1], ' '); q = ppm_put(q, v[k][2], '\n'); }
-    }
-    if (blockIdx.x == 0) { for (int k = threadIdx.x; k < a.header_len; k += kPpmBlock) a.text[k] = a.header[k]; }
-    __syncthreads();
-    char* dst_al = dst - shift;
-    const uint32_t end = shift + total;                  // text occupies LDS bytes [shift, end)
-    const uint32_t w_first = (shift + 3u) / 4u, w_last = end / 4u;      // whole dwords [w_first, w_last)
-    const uint32_t* s_words = reinterpret_cast<const uint32_t*>(s_text);
-    uint32_t* g_words = reinterpret_cast<uint32_t*>(dst_al);
-    for (uint32_t w = w_first + threadIdx.x; w < w_last; w += kPpmBlock) g_words[w] = s_words[w];
-    // bytes before the first whole dword and after the last one (a neighbouring block owns the rest of those dwords)
-    if (threadIdx.x < 8) {
-        const uint32_t head_end = w_first * 4u < end ? w_first * 4u : end;
-        const uint32_t tail_begin = w_last * 4u > head_end ? w_last * 4u : head_end;
-        const uint32_t b = threadIdx.x < 4 ? shift + threadIdx.x : tail_begin + (threadIdx.x - 4u);
-        const bool ok = threadIdx.x < 4 ? b < head_end : b < end;
-        if (ok) dst_al[b] = s_text[b];
-    }
-}
-
-struct rt_context {
-    int device = -1;
-    std::string error;
-    float4* d_geom = nullptr; float4* d_mat = nullptr; Aux* d_aux = nullptr; int n = 0;
-    float4* d_frec = nullptr; float4* d_prec = nullptr; float plane_s0 = 0.0f; float plane_rmin = 1.0f; int n_pad = 0;
-    bool plane_filter = true;
-    bool records_in_lds = false;      // measurement variant, RT_AMD_RECORDS=lds
-    float* d_samples = nullptr; size_t samples_bytes = 0;      // sample buffer of the persistent megakernel
-    float* d_accum = nullptr; size_t accum_bytes = 0;          // running per-pixel sums across sample batches
-    unsigned int* d_work = nullptr;
-    uint16_t* d_stacks = nullptr; size_t stacks_lanes = 0;
-    float* d_staging = nullptr;
-    uint32_t* d_tile_cls = nullptr; uint32_t* d_tile_order = nullptr; size_t tile_cap = 0;   // work order of the tiles of the current call
-    bool tile_ordering = true;
-    // the order depends on scene, camera and the rows rendered only: it is kept for repeated calls (new seeds, more samples)
-    struct TileKey { uint64_t scene_version, camera_version; int32_t width, height, band_rows, band_first, band_step; float tmin; } tile_key{};
-    bool tile_key_valid = false; uint64_t scene_version = 0, camera_version = 0;
-    // wavefront mode pool
-    uint32_t wf_P = 0; float* wf_ray = nullptr; uint32_t* wf_pixsmp = nullptr; int* wf_depth = nullptr; float* wf_hit_t = nullptr; int* wf_hit_idx = nullptr;
-    uint16_t* wf_stacks = nullptr; uint32_t* wf_q[2] = { nullptr, nullptr }; uint32_t* wf_n = nullptr;
-    int wf_blocks_per_cu[4] = { 0, 0, 0, 0 };
-    int num_cu = 0; int trace_blocks_per_cu[5] = { 0, 0, 0, 0, 0 };
-    bool have_camera = false; CameraD cam{};
-    unsigned long long* d_rays = nullptr;      // [0] closest-hit queries, [1] those that hit nothing
-    uint64_t last_samples = 0;                // primary rays of the last render (owned pixels x spp)
-    float* d_out_rgb = nullptr; int32_t* d_out_irgb = nullptr; size_t out_rgb_bytes = 0, out_irgb_bytes = 0;   // device side of rt_render's host outputs (grow-only)
-    void* d_ppm_scratch = nullptr; size_t ppm_scratch_bytes = 0;    // per-block lengths and offsets of the PPM encoder
-    hipEvent_t ev0 = nullptr, ev1 = nullptr; hipStream_t last_stream = nullptr; bool pending = false;
-};
-
 static thread_local std::string g_error;
 
-static int fail(rt_context* ctx, int code, const char* fmt, ...)
+int fail(rt_context* ctx, int code, const char* fmt, ...)
 {
     char buf[512];
     va_list ap; va_start(ap, fmt); vsnprintf(buf, sizeof buf, fmt, ap); va_end(ap);
     if (ctx) ctx->error = buf; else g_error = buf;
     return code;
-}
-#define HIP_TRY(ctx, call) do { hipError_t e_ = (call); if (e_ != hipSuccess) return fail(ctx, RT_ERR_HIP, "%s failed: %s", #call, hipGetErrorString(e_)); } while (0)
-
-static CameraD to_device(const rt_camera_pod& c)
-{
-    CameraD d;
-    d.origin = { c.origin[0], c.origin[1], c.origin[2] };
-    d.llc = { c.lower_left_corner[0], c.lower_left_corner[1], c.lower_left_corner[2] };
-    d.horiz = { c.horizontal[0], c.horizontal[1], c.horizontal[2] };
-    d.vert = { c.vertical[0], c.vertical[1], c.vertical[2] };
-    d.u = { c.u[0], c.u[1], c.u[2] };
-    d.v = { c.v[0], c.v[1], c.v[2] };
-    d.lens_radius = c.lens_radius;
-    return d;
-}
-
-static bool params_ok(const rt_params* p)
-{
-    return p && p->width > 0 && p->height > 0 && p->spp > 0 && p->max_depth >= 0 && p->max_depth <= RT_MAX_DEPTH &&
-           p->band_rows > 0 && p->band_first >= 0 && p->band_step > 0 &&
-           (p->mode == RT_MODE_MEGAKERNEL || p->mode == RT_MODE_WAVEFRONT || p->mode == RT_MODE_PIXEL);
-}
-
-namespace {
-struct DevBuf {
-    void* p = nullptr;
-    ~DevBuf() { if (p) (void)hipFree(p); }
-    hipError_t up(const void* h, size_t bytes) { hipError_t e = hipMalloc(&p, bytes ? bytes : 4); if (e == hipSuccess && h && bytes) e = hipMemcpy(p, h, bytes, hipMemcpyHostToDevice); return e; }
-    hipError_t down(void* h, size_t bytes) { return hipMemcpy(h, p, bytes, hipMemcpyDeviceToHost); }
-    template <class T> T* as() { return static_cast<T*>(p); }
-};
 }
 
 #ifdef RT_SECTION_TIMERS
@@ -1586,248 +1335,6 @@ int rt_render(rt_context* ctx, const rt_params* p, float* h_rgb_mean, int32_t* h
     if (rc == RT_OK && d_rgb) { hipError_t e = hipMemcpy(h_rgb_mean, d_rgb, npx * 3 * sizeof(float), hipMemcpyDeviceToHost); if (e != hipSuccess) rc = fail(ctx, RT_ERR_HIP, "rt_render: copy back: %s", hipGetErrorString(e)); }
     if (rc == RT_OK && d_i) { hipError_t e = hipMemcpy(h_irgb, d_i, npx * 3 * sizeof(int32_t), hipMemcpyDeviceToHost); if (e != hipSuccess) rc = fail(ctx, RT_ERR_HIP, "rt_render: copy back: %s", hipGetErrorString(e)); }
     return rc;
-}
-
-// ---------------------------------------------------------------------------- scene setup
-static void philox_host(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, uint32_t k0, uint32_t k1, uint32_t out[4])
-{
-    for (int r = 0; r < 10; ++r) {
-        const uint64_t p0 = (uint64_t)0xD2511F53u * c0, p1 = (uint64_t)0xCD9E8D57u * c2;
-        const uint32_t n0 = (uint32_t)(p1 >> 32) ^ c1 ^ k0, n2 = (uint32_t)(p0 >> 32) ^ c3 ^ k1;
-        c0 = n0; c1 = (uint32_t)p1; c2 = n2; c3 = (uint32_t)p0;
-        k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
-    }
-    out[0] = c0; out[1] = c1; out[2] = c2; out[3] = c3;
-}
-
-int rt_scene_grid(uint64_t seed, int half_extent, int max_small, float* table9, int cap, int* n_out)
-{
-    if (!table9 || !n_out || half_extent <= 0 || half_extent > 1024 || max_small < 0 || cap < 4) return fail(nullptr, RT_ERR_INVALID, "rt_scene_grid: bad argument");
-    const uint32_t k0 = (uint32_t)seed, k1 = (uint32_t)(seed >> 32);
-    int n = 0;
-    auto put = [&](float x, float y, float z, float r, int m, float ar, float ag, float ab, float p) {
-        float* row = table9 + (size_t)n * 9;
-        row[0] = x; row[1] = y; row[2] = z; row[3] = r; row[4] = (float)m; row[5] = ar; row[6] = ag; row[7] = ab; row[8] = p; ++n;
-    };
-    auto u01h = [](uint32_t w) { return (float)(w >> 8) * (1.0f / 16777216.0f); };
-    put(0.0f, -1000.0f, 0.0f, 1000.0f, RT_LAMBERTIAN, 0.5f, 0.5f, 0.5f, 0.0f);
-    const int side = 2 * half_extent;
-    int kept = 0;
-    for (int a = -half_extent; a < half_extent && kept < max_small; ++a) {
-        for (int b = -half_extent; b < half_extent && kept < max_small; ++b) {
-            const uint32_t t = (uint32_t)((a + half_extent) * side + (b + half_extent));
-            uint32_t w0[4], w1[4], w2[4];
-            philox_host(t, 0, 0, 0, k0, k1, w0);
-            const float choose = u01h(w0[0]);
-            const float x = (float)a + 0.9f * u01h(w0[1]), z = (float)b + 0.9f * u01h(w0[2]);
-            const float dx = x - 4.0f, dy = 0.2f - 0.2f, dz = z - 0.0f;
-            if (!(sqrtf(dx * dx + dy * dy + dz * dz) > 0.9f)) continue;
-            if (n + 4 > cap) return fail(nullptr, RT_ERR_TOO_LARGE, "rt_scene_grid: table capacity %d too small", cap);
-            philox_host(t, 1, 0, 0, k0, k1, w1);
-            if (choose < 0.8f) {
-                philox_host(t, 2, 0, 0, k0, k1, w2);
-                put(x, 0.2f, z, 0.2f, RT_LAMBERTIAN, u01h(w1[0]) * u01h(w1[1]), u01h(w1[2]) * u01h(w1[3]), u01h(w2[0]) * u01h(w2[1]), 0.0f);
-            } else if (choose < 0.95f) {
-                put(x, 0.2f, z, 0.2f, RT_METAL, 0.5f * (1.0f + u01h(w1[0])), 0.5f * (1.0f + u01h(w1[1])), 0.5f * (1.0f + u01h(w1[2])), 0.5f * u01h(w1[3]));
-            } else {
-                put(x, 0.2f, z, 0.2f, RT_DIELECTRIC, 1.0f, 1.0f, 1.0f, 1.5f);
-            }
-            ++kept;
-        }
-    }
-    if (n + 3 > cap) return fail(nullptr, RT_ERR_TOO_LARGE, "rt_scene_grid: table capacity %d too small", cap);
-    put(0.0f, 1.0f, 0.0f, 1.0f, RT_DIELECTRIC, 1.0f, 1.0f, 1.0f, 1.5f);
-    put(-4.0f, 1.0f, 0.0f, 1.0f, RT_LAMBERTIAN, 0.4f, 0.2f, 0.1f, 0.0f);
-    put(4.0f, 1.0f, 0.0f, 1.0f, RT_METAL, 0.7f, 0.6f, 0.5f, 0.0f);
-    *n_out = n;
-    return RT_OK;
-}
-
-// ---------------------------------------------------------------------------- output.ppm
-static inline char* put_int(char* q, int32_t v)
-{
-    char tmp[12]; int n = 0;
-    uint32_t u = v < 0 ? 0u - (uint32_t)v : (uint32_t)v;
-    do { tmp[n++] = (char)('0' + u % 10); u /= 10; } while (u);
-    if (v < 0) *q++ = '-';
-    while (n) *q++ = tmp[--n];
-    return q;
-}
-
-}   // extern "C"
-namespace {
-// Decimal text of 0..255 (what the quantiser produces for radiance in [0, 1]): up to three digits in the
-// low bytes of a word, so that a value is emitted with one 4-byte store.
-struct ByteText {
-    uint32_t word[256]; uint8_t len[256];
-    ByteText() { for (int v = 0; v < 256; ++v) { char t[8] = { 0 }; len[v] = (uint8_t)(put_int(t, v) - t); memcpy(&word[v], t, 4); } }
-};
-const ByteText& byte_text() { static const ByteText t; return t; }
-inline int int_length(const ByteText& bt, int32_t v) { char t[16]; return (uint32_t)v < 256u ? bt.len[v] : (int)(put_int(t, v) - t); }
-}
-extern "C" {
-
-int64_t rt_format_ppm(const int32_t* irgb, int width, int height, char* buf, int64_t cap)
-{
-    if (!irgb || width <= 0 || height <= 0) return 0;
-    const ByteText& bt = byte_text();
-    const int64_t ints = (int64_t)width * height * 3;
-    const int64_t worst = 32 + (int64_t)width * height * 36;   // three ints of up to 11 chars + separators
-    char head[48];
-    const int hn = snprintf(head, sizeof head, "P3\n%d %d\n255\n", width, height);
-    if (!buf || cap < worst) {
-        // exact size pass
-        int64_t need = hn + ints;
-        for (int64_t k = 0; k < ints; ++k) need += int_length(bt, irgb[k]);
-        if (!buf || cap < need) return -need;
-    }
-    char* q = buf; memcpy(q, head, hn); q += hn;
-    char* const end = buf + cap;
-    auto emit = [&](int32_t v, char sep) {
-        if ((uint32_t)v < 256u && end - q >= 8) { memcpy(q, &bt.word[v], 4); q += bt.len[v]; }    // the store may spill up to 3 bytes past the digits
-        else q = put_int(q, v);
-        *q++ = sep;
-    };
-    for (int64_t k = 0; k < ints; k += 3) { emit(irgb[k], ' '); emit(irgb[k + 1], ' '); emit(irgb[k + 2], '\n'); }
-    return q - buf;
-}
-
-int rt_write_ppm(const char* path, const int32_t* irgb, int width, int height)
-{
-    if (!path || !irgb || width <= 0 || height <= 0) return fail(nullptr, RT_ERR_INVALID, "rt_write_ppm: bad argument");
-    const int64_t need = -rt_format_ppm(irgb, width, height, nullptr, 0);
-    std::vector<char> buf((size_t)need);
-    const int64_t n = rt_format_ppm(irgb, width, height, buf.data(), need);
-    FILE* f = fopen(path, "wb");
-    if (!f) return fail(nullptr, RT_ERR_INVALID, "rt_write_ppm: cannot open %s", path);
-    const size_t w = fwrite(buf.data(), 1, (size_t)n, f);
-    fclose(f);
-    return w == (size_t)n ? RT_OK : fail(nullptr, RT_ERR_INVALID, "rt_write_ppm: short write to %s", path);
-}
-
-int rt_encode_ppm_device(rt_context* ctx, const int32_t* d_irgb, int width, int height, char* d_text, int64_t cap, int64_t* bytes, void* stream)
-{
-    if (!ctx) return fail(nullptr, RT_ERR_INVALID, "rt_encode_ppm_device: null context");
-    if (!d_irgb || width <= 0 || height <= 0 || !bytes) return fail(ctx, RT_ERR_INVALID, "rt_encode_ppm_device: bad argument");
-    const uint64_t pixels64 = (uint64_t)width * (uint64_t)height;
-    if (pixels64 > 0x40000000ull) return fail(ctx, RT_ERR_TOO_LARGE, "rt_encode_ppm_device: more than 2^30 pixels");
-    HIP_TRY(ctx, hipSetDevice(ctx->device));
-    hipStream_t st = static_cast<hipStream_t>(stream);
-    PpmArgs a{};
-    a.irgb = d_irgb; a.pixels = (uint32_t)pixels64;
-    a.blocks = (a.pixels + kPpmPxPerBlock - 1) / kPpmPxPerBlock;
-    a.header_len = snprintf(a.header, sizeof a.header, "P3\n%d %d\n255\n", width, height);
-    const size_t off_bytes = ((size_t)a.blocks + 1) * sizeof(unsigned long long), need = off_bytes + (size_t)a.blocks * sizeof(uint32_t);
-    if (ctx->ppm_scratch_bytes < need) {
-        (void)hipFree(ctx->d_ppm_scratch); ctx->d_ppm_scratch = nullptr; ctx->ppm_scratch_bytes = 0;
-        HIP_TRY(ctx, hipMalloc(&ctx->d_ppm_scratch, need));
-        ctx->ppm_scratch_bytes = need;
-    }
-    a.block_off = static_cast<unsigned long long*>(ctx->d_ppm_scratch);
-    a.block_len = reinterpret_cast<uint32_t*>(static_cast<char*>(ctx->d_ppm_scratch) + off_bytes);
-    a.text = d_text;
-    hipLaunchKernelGGL(k_ppm_len, dim3(a.blocks), dim3(kPpmBlock), 0, st, a);
-    hipLaunchKernelGGL(k_ppm_scan, dim3(1), dim3(1024), 0, st, a);
-    HIP_TRY(ctx, hipGetLastError());
-    unsigned long long body = 0;
-    HIP_TRY(ctx, hipMemcpyAsync(&body, a.block_off + a.blocks, sizeof body, hipMemcpyDeviceToHost, st));
-    HIP_TRY(ctx, hipStreamSynchronize(st));
-    *bytes = (int64_t)body + a.header_len;
-    if (!d_text || cap < *bytes) return fail(ctx, RT_ERR_TOO_LARGE, "rt_encode_ppm_device: the text needs %lld bytes, capacity is %lld", (long long)*bytes, (long long)cap);
-    hipLaunchKernelGGL(k_ppm_write, dim3(a.blocks), dim3(kPpmBlock), 0, st, a);
-    HIP_TRY(ctx, hipGetLastError());
-    return RT_OK;
-}
-
-int rt_write_ppm_device(rt_context* ctx, const char* path, const int32_t* d_irgb, int width, int height, void* stream)
-{
-    if (!ctx) return fail(nullptr, RT_ERR_INVALID, "rt_write_ppm_device: null context");
-    if (!path) return fail(ctx, RT_ERR_INVALID, "rt_write_ppm_device: null path");
-    int64_t bytes = 0;
-    // size query first (no text buffer), then the encode into a buffer of exactly that size
-    int rc = rt_encode_ppm_device(ctx, d_irgb, width, height, nullptr, 0, &bytes, stream);
-    if (rc != RT_ERR_TOO_LARGE || bytes <= 0) return rc == RT_OK ? fail(ctx, RT_ERR_INVALID, "rt_write_ppm_device: empty image") : rc;
-    DevBuf text;
-    HIP_TRY(ctx, text.up(nullptr, (size_t)bytes + 8));
-    rc = rt_encode_ppm_device(ctx, d_irgb, width, height, text.as<char>(), bytes, &bytes, stream);
-    if (rc != RT_OK) return rc;
-    std::vector<char> host((size_t)bytes);
-    hipStream_t st = static_cast<hipStream_t>(stream);
-    HIP_TRY(ctx, hipMemcpyAsync(host.data(), text.p, (size_t)bytes, hipMemcpyDeviceToHost, st));
-    HIP_TRY(ctx, hipStreamSynchronize(st));
-    FILE* f = fopen(path, "wb");
-    if (!f) return fail(ctx, RT_ERR_INVALID, "rt_write_ppm_device: cannot open %s", path);
-    const size_t w = fwrite(host.data(), 1, host.size(), f);
-    const int closed = fclose(f);
-    return (w == host.size() && closed == 0) ? RT_OK : fail(ctx, RT_ERR_INVALID, "rt_write_ppm_device: short write to %s", path);
-}
-
-// ---------------------------------------------------------------------------- unit-level entry points
-
-int rt_test_sphere_hit(rt_context* ctx, int n, const float* ray_o, const float* ray_d, const float* center, const float* radius,
-                       const float* tmin, const float* tmax, int32_t* hit, float* t, float* p, float* normal)
-{
-    if (!ctx) return fail(nullptr, RT_ERR_INVALID, "rt_test_sphere_hit: null context");
-    if (n <= 0 || !ray_o || !ray_d || !center || !radius || !tmin || !tmax || !hit || !t || !p || !normal) return fail(ctx, RT_ERR_INVALID, "rt_test_sphere_hit: bad argument");
-    HIP_TRY(ctx, hipSetDevice(ctx->device));
-    DevBuf o, d, c, r, a, b, oh, ot, op, on;
-    const size_t f3 = sizeof(float) * 3 * n, f1 = sizeof(float) * n;
-    HIP_TRY(ctx, o.up(ray_o, f3)); HIP_TRY(ctx, d.up(ray_d, f3)); HIP_TRY(ctx, c.up(center, f3)); HIP_TRY(ctx, r.up(radius, f1));
-    HIP_TRY(ctx, a.up(tmin, f1)); HIP_TRY(ctx, b.up(tmax, f1));
-    HIP_TRY(ctx, oh.up(nullptr, sizeof(int32_t) * n)); HIP_TRY(ctx, ot.up(nullptr, f1)); HIP_TRY(ctx, op.up(nullptr, f3)); HIP_TRY(ctx, on.up(nullptr, f3));
-    hipLaunchKernelGGL(k_test_sphere_hit, dim3((n + 63) / 64), dim3(64), 0, 0, n, o.as<float>(), d.as<float>(), c.as<float>(), r.as<float>(),
-                       a.as<float>(), b.as<float>(), oh.as<int32_t>(), ot.as<float>(), op.as<float>(), on.as<float>());
-    HIP_TRY(ctx, hipGetLastError()); HIP_TRY(ctx, hipDeviceSynchronize());
-    HIP_TRY(ctx, oh.down(hit, sizeof(int32_t) * n)); HIP_TRY(ctx, ot.down(t, f1)); HIP_TRY(ctx, op.down(p, f3)); HIP_TRY(ctx, on.down(normal, f3));
-    return RT_OK;
-}
-
-int rt_test_scatter(rt_context* ctx, int n, const int32_t* material, const float* albedo_rgb, const float* param, const float* ray_o,
-                    const float* ray_d, const float* hit_p, const float* hit_n, const int32_t* draws, int draws_per_case,
-                    int32_t* ret, float* attenuation, float* out_o, float* out_d, int32_t* used)
-{
-    if (!ctx) return fail(nullptr, RT_ERR_INVALID, "rt_test_scatter: null context");
-    if (n <= 0 || draws_per_case <= 0 || !material || !albedo_rgb || !param || !ray_o || !ray_d || !hit_p || !hit_n || !draws || !ret || !attenuation || !out_o || !out_d || !used)
-        return fail(ctx, RT_ERR_INVALID, "rt_test_scatter: bad argument");
-    for (int i = 0; i < n; ++i) if (material[i] < 0 || material[i] > 2) return fail(ctx, RT_ERR_INVALID, "rt_test_scatter: unknown material %d", material[i]);
-    HIP_TRY(ctx, hipSetDevice(ctx->device));
-    DevBuf m, al, pa, o, d, hp, hn, dr, r, at, oo, od, us;
-    const size_t f3 = sizeof(float) * 3 * n, f1 = sizeof(float) * n, i1 = sizeof(int32_t) * n;
-    HIP_TRY(ctx, m.up(material, i1)); HIP_TRY(ctx, al.up(albedo_rgb, f3)); HIP_TRY(ctx, pa.up(param, f1)); HIP_TRY(ctx, o.up(ray_o, f3));
-    HIP_TRY(ctx, d.up(ray_d, f3)); HIP_TRY(ctx, hp.up(hit_p, f3)); HIP_TRY(ctx, hn.up(hit_n, f3)); HIP_TRY(ctx, dr.up(draws, sizeof(int32_t) * (size_t)n * draws_per_case));
-    HIP_TRY(ctx, r.up(nullptr, i1)); HIP_TRY(ctx, at.up(nullptr, f3)); HIP_TRY(ctx, oo.up(nullptr, f3)); HIP_TRY(ctx, od.up(nullptr, f3)); HIP_TRY(ctx, us.up(nullptr, i1));
-    hipLaunchKernelGGL(k_test_scatter, dim3((n + 63) / 64), dim3(64), 0, 0, n, m.as<int32_t>(), al.as<float>(), pa.as<float>(), o.as<float>(), d.as<float>(),
-                       hp.as<float>(), hn.as<float>(), dr.as<int32_t>(), draws_per_case, r.as<int32_t>(), at.as<float>(), oo.as<float>(), od.as<float>(), us.as<int32_t>());
-    HIP_TRY(ctx, hipGetLastError()); HIP_TRY(ctx, hipDeviceSynchronize());
-    HIP_TRY(ctx, r.down(ret, i1)); HIP_TRY(ctx, at.down(attenuation, f3)); HIP_TRY(ctx, oo.down(out_o, f3)); HIP_TRY(ctx, od.down(out_d, f3)); HIP_TRY(ctx, us.down(used, i1));
-    return RT_OK;
-}
-
-int rt_test_get_ray(rt_context* ctx, int n, const rt_camera_pod* cam, const float* s, const float* t, const float* disk_xy, float* ray_o, float* ray_d)
-{
-    if (!ctx) return fail(nullptr, RT_ERR_INVALID, "rt_test_get_ray: null context");
-    if (n <= 0 || !cam || !s || !t || !disk_xy || !ray_o || !ray_d) return fail(ctx, RT_ERR_INVALID, "rt_test_get_ray: bad argument");
-    HIP_TRY(ctx, hipSetDevice(ctx->device));
-    DevBuf ds, dt, dd, o, d;
-    const size_t f3 = sizeof(float) * 3 * n, f1 = sizeof(float) * n;
-    HIP_TRY(ctx, ds.up(s, f1)); HIP_TRY(ctx, dt.up(t, f1)); HIP_TRY(ctx, dd.up(disk_xy, 2 * f1)); HIP_TRY(ctx, o.up(nullptr, f3)); HIP_TRY(ctx, d.up(nullptr, f3));
-    hipLaunchKernelGGL(k_test_get_ray, dim3((n + 63) / 64), dim3(64), 0, 0, n, to_device(*cam), ds.as<float>(), dt.as<float>(), dd.as<float>(), o.as<float>(), d.as<float>());
-    HIP_TRY(ctx, hipGetLastError()); HIP_TRY(ctx, hipDeviceSynchronize());
-    HIP_TRY(ctx, o.down(ray_o, f3)); HIP_TRY(ctx, d.down(ray_d, f3));
-    return RT_OK;
-}
-
-int rt_test_philox(rt_context* ctx, int n, const uint32_t* ctr, const uint32_t* key, uint32_t* out)
-{
-    if (!ctx) return fail(nullptr, RT_ERR_INVALID, "rt_test_philox: null context");
-    if (n <= 0 || !ctr || !key || !out) return fail(ctx, RT_ERR_INVALID, "rt_test_philox: bad argument");
-    HIP_TRY(ctx, hipSetDevice(ctx->device));
-    DevBuf c, o;
-    HIP_TRY(ctx, c.up(ctr, sizeof(uint32_t) * 4 * n)); HIP_TRY(ctx, o.up(nullptr, sizeof(uint32_t) * 4 * n));
-    hipLaunchKernelGGL(k_test_philox, dim3((n + 63) / 64), dim3(64), 0, 0, n, c.as<uint32_t>(), key[0], key[1], o.as<uint32_t>());
-    HIP_TRY(ctx, hipGetLastError()); HIP_TRY(ctx, hipDeviceSynchronize());
-    HIP_TRY(ctx, o.down(out, sizeof(uint32_t) * 4 * n));
-    return RT_OK;
 }
 
 }  // extern "C"
