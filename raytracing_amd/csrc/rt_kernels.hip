@@ -1105,8 +1105,9 @@ int rt_render_device(rt_context* ctx, const rt_params* p, float* d_rgb_mean, int
     } else if (owned > 0) {
         const int tiles_x = (p->width + 7) / 8, tiles_y = (owned + 7) / 8;
         const uint64_t Q = (uint64_t)tiles_x * tiles_y * 64;
-        // sample batches: the per-batch sample buffer stays below 4 GiB and item ids below 2^31
-        uint64_t per_batch = (4ull << 30) / (Q * 12);
+        // sample batches: the per-batch sample buffer stays below 16 GiB (of 288 GB of HBM) and item ids below 2^31;
+        // every batch ends with the drain of its longest paths, so fewer, larger batches are better
+        uint64_t per_batch = (16ull << 30) / (Q * 12);
         if (per_batch > (1ull << 31) / Q) per_batch = (1ull << 31) / Q;
         if (per_batch == 0) return fail(ctx, RT_ERR_TOO_LARGE, "rt_render_device: %llu pixels in one call exceed the sample-buffer limit; split the image into bands", (unsigned long long)Q);
         const int batches = (int)((p->spp + per_batch - 1) / per_batch);
