@@ -339,45 +339,45 @@ __device__ __forceinline__ void closest_hit(const RayD& ray, float tmin, const S
         // (sphere.cpp:27-50, hittablelist.cpp:21-29) for what is left, in ascending index order.
         // Splitting keeps the square root and the two divisions out of the long first loop, where
         // some lane of the wave would otherwise need them on every trip.
+        // Every word flagged in nz is non-zero, and padding records never pass the filter, so each bit
+        // visited names a real sphere (k < n).
         uint32_t nzb = 0u;
-        {
-            uint32_t cand = 0u, keep = 0u; int cbase = 0, w = -1;
+        if (nz != 0u) {
+            int w = __builtin_clz(nz);
+            nz &= ~(0x80000000u >> w);
+            uint32_t cand = mask_words[w * 64], keep = 0u;
+            int cbase = sbase + (w << 5);
             for (;;) {
+                const int jj = __builtin_clz(cand);
+                const uint32_t bit = 0x80000000u >> jj;
+                cand &= ~bit;
+                const int k = cbase + jj;
+                const float4 g = kLds ? s_geom[k] : sw.geom[k];
+                const V3 oc = ray.o - mk(g.x, g.y, g.z);
+                const float b = dot(oc, ray.d);
+                const float cc = dot(oc, oc) - g.w;
+                const float desc = b * b - qa * cc;
+                if (desc > 0.0f) keep |= bit;
                 if (cand == 0u) {
-                    if (w >= 0) { mask_words[w * 64] = keep; if (keep) nzb |= 0x80000000u >> w; }
+                    mask_words[w * 64] = keep;
+                    nzb |= keep ? 0x80000000u >> w : 0u;
                     if (nz == 0u) break;
-                    w = __clz((int)nz);
+                    w = __builtin_clz(nz);
                     nz &= ~(0x80000000u >> w);
                     cand = mask_words[w * 64];
                     keep = 0u;
                     cbase = sbase + (w << 5);
                 }
-                const int jj = __clz((int)cand);
-                const uint32_t bit = 0x80000000u >> jj;
-                cand &= ~bit;
-                const int k = cbase + jj;
-                if (k < sw.n) {
-                    const float4 g = kLds ? s_geom[k] : sw.geom[k];
-                    const V3 oc = ray.o - mk(g.x, g.y, g.z);
-                    const float b = dot(oc, ray.d);
-                    const float cc = dot(oc, oc) - g.w;
-                    const float desc = b * b - qa * cc;
-                    if (desc > 0.0f) keep |= bit;
-                }
             }
         }
         T.mark(2);
-        {
-            uint32_t cand = 0u; int cbase = 0;
+        if (nzb != 0u) {
+            int w = __builtin_clz(nzb);
+            nzb &= ~(0x80000000u >> w);
+            uint32_t cand = mask_words[w * 64];
+            int cbase = sbase + (w << 5);
             for (;;) {
-                if (cand == 0u) {
-                    if (nzb == 0u) break;
-                    const int w = __clz((int)nzb);
-                    nzb &= ~(0x80000000u >> w);
-                    cand = mask_words[w * 64];
-                    cbase = sbase + (w << 5);
-                }
-                const int jj = __clz((int)cand);
+                const int jj = __builtin_clz(cand);
                 cand &= ~(0x80000000u >> jj);
                 const int k = cbase + jj;
                 const float4 g = kLds ? s_geom[k] : sw.geom[k];
@@ -389,6 +389,13 @@ __device__ __forceinline__ void closest_hit(const RayD& ray, float tmin, const S
                 float temp = (-b - sq) / qa;
                 if (!(temp < closest && temp > tmin)) temp = (-b + sq) / qa;
                 if (temp < closest && temp > tmin) { closest = temp; hit = k; }
+                if (cand == 0u) {
+                    if (nzb == 0u) break;
+                    w = __builtin_clz(nzb);
+                    nzb &= ~(0x80000000u >> w);
+                    cand = mask_words[w * 64];
+                    cbase = sbase + (w << 5);
+                }
             }
         }
         T.mark(3);
@@ -1048,7 +1055,10 @@ int rt_upload_scene(rt_context* ctx, int n, const float* cx, const float* cy, co
     HIP_TRY(ctx, hipMalloc(&ctx->d_frec, sizeof(float4) * n_pad));
     HIP_TRY(ctx, hipMemcpy(ctx->d_frec, frec.data(), sizeof(float4) * n_pad, hipMemcpyHostToDevice));
     ctx->n_pad = n_pad;
-    HIP_TRY(ctx, hipMalloc(&ctx->d_geom, sizeof(float4) * n));
+    // n_pad entries: a ray with a NaN direction passes every filter record, padding included, and the exact pass
+    // then reads geom[k] for k up to n_pad - 1 (the NaN discriminant rejects it)
+    HIP_TRY(ctx, hipMalloc(&ctx->d_geom, sizeof(float4) * n_pad));
+    HIP_TRY(ctx, hipMemset(ctx->d_geom, 0, sizeof(float4) * n_pad));
     HIP_TRY(ctx, hipMalloc(&ctx->d_mat, sizeof(float4) * n));
     HIP_TRY(ctx, hipMalloc(&ctx->d_aux, sizeof(Aux) * n));
     HIP_TRY(ctx, hipMemcpy(ctx->d_geom, geom.data(), sizeof(float4) * n, hipMemcpyHostToDevice));
