@@ -171,18 +171,20 @@ __global__ void __launch_bounds__(kBlock) k_render_mega(const RenderArgs a)
 // lane's path ends it is handed the next item (ballot + prefix count), so every trip of the main
 // loop runs one closest-hit sweep with all lanes busy until the work runs out.
 //
-// The sweep is split in two:
-//   filter  (hot, 8 FMAs + 1 bit op per ray-sphere pair, branch-free, scene records in SGPRs or
-//            LDS): a conservative sign test of the discriminant, expanded about the world origin,
+// The sweep (closest_hit) is split in two:
+//   filter  (hot, branch-free, records as scalar operands): a conservative sign test per ray-sphere
+//            pair -- by default the distance of the centre to the vertical plane through the ray
+//            (3 FMAs), alternatively the whole discriminant expanded about the world origin (8 FMAs) --
 //            with a per-sphere and per-ray slack that dominates every rounding error of both this
 //            form and the reference's.  The sign bits of 32 spheres are shifted into one register.
 //   exact   (cold): the few spheres whose bit says "maybe" are evaluated with the reference's own
-//            unfused arithmetic (sphere.cpp:15-52) in ascending index order with the shrinking
-//            upper bound of hittablelist.cpp:13-31, so the chosen sphere and t are bit-identical.
+//            unfused arithmetic (sphere.cpp:15-52); the accepted root of each and the running minimum
+//            follow hittablelist.cpp:13-31, so the chosen sphere and t are bit-identical.
+// A wave left with only a few live paths (the end of a launch) switches to closest_hit_few.
 struct TraceArgs {
     const float4* prec;      // plane-filter records (cx, cz, R_i = r^2 + slack_i, 0), same padding as frec
     float plane_s0, plane_rmin;   // plane filter: constant part of the per-ray slack, smallest R_i
-    const float4* frec;      // filter records (cx, cy, cz, |c|^2 - r^2 - slack), padded to a multiple of 32
+    const float4* frec;      // discriminant-filter records (cx, cy, cz, |c|^2 - r^2 - slack), padded to a multiple of 8
     const float4* geom; const float4* mat; const Aux* aux; int n, n_pad;
     CameraD cam;
     int width, height, max_depth; float tmin;
