@@ -194,6 +194,8 @@ struct TraceArgs {
     int s_begin, s_count;                 // sample batch
     uint32_t total_items;                 // Q * s_count  (< 2^31)
     int chunk_items;                      // items a wave reserves per atomic: a multiple of 64, at most kChunkItems
+    uint32_t resident_waves;              // waves of this launch that run at the same time
+    uint32_t min_chunk_items;             // smallest chunk taken near the end of the work (a multiple of 64)
     float* samples;                       // [total_items][3]
     unsigned long long* ray_counter;
     unsigned int* work_counter;
@@ -204,11 +206,13 @@ struct TraceArgs {
 
 // Diagnostic build (-DRT_SECTION_TIMERS): every wave accumulates s_memtime ticks per section of the
 // main loop into g_section_ticks.  Never enabled in the shipped library (mark() is empty there).
-#ifdef RT_SECTION_TIMERS
-__device__ unsigned long long g_section_ticks[8];
-// per wave of the last k_trace launch: s_memrealtime (100 MHz, common to all XCDs) at entry, when the wave first found the work counter dry, at exit;
+#ifdef RT_WAVE_TIMELINE
+// Diagnostic build (-DRT_WAVE_TIMELINE), per wave of the last k_trace launch: s_memrealtime (100 MHz, common to all XCDs) at entry, when the wave first found the work counter dry, at exit;
 // and how many trips of the main loop it made after that point
 __device__ unsigned long long g_wave_times[6][8192];      // rows 4, 5: trips made with the sparse sweep, ticks spent in those trips (whole trip)
+#endif
+#ifdef RT_SECTION_TIMERS
+__device__ unsigned long long g_section_ticks[8];
 struct SecTimer {
     unsigned long long acc[8]; unsigned long long last;
     __device__ __forceinline__ void start() { for (int k = 0; k < 8; ++k) acc[k] = 0; last = __builtin_amdgcn_s_memtime(); }
@@ -652,11 +656,11 @@ __global__ void __launch_bounds__(kTraceBlock) k_trace(const TraceArgs a)
     ig.owned_rows = a.owned_rows; ig.tiles_x = a.tiles_x; ig.Q = a.Q; ig.s_begin = a.s_begin; ig.s_count = a.s_count; ig.tile_order = a.tile_order;
     SweepScene sw; sw.frec = a.frec; sw.prec = a.prec; sw.plane_s0 = a.plane_s0; sw.plane_rmin = a.plane_rmin; sw.geom = a.geom; sw.n = a.n; sw.n_pad = a.n_pad;
 
-#ifdef RT_SECTION_TIMERS
+#ifdef RT_WAVE_TIMELINE
     const unsigned long long t_enter = __builtin_amdgcn_s_memrealtime(); unsigned long long t_dry = 0, trips_dry = 0, sparse_trips = 0, sparse_ticks = 0, t_trip = 0; bool was_sparse = false;
 #endif
     for (;;) {
-#ifdef RT_SECTION_TIMERS
+#ifdef RT_WAVE_TIMELINE
         if (exhausted) { if (t_dry == 0) t_dry = __builtin_amdgcn_s_memrealtime(); ++trips_dry; }
         { const unsigned long long now = __builtin_amdgcn_s_memrealtime(); if (was_sparse) { ++sparse_trips; sparse_ticks += now - t_trip; } t_trip = now; was_sparse = false; }
 #endif
@@ -665,11 +669,22 @@ __global__ void __launch_bounds__(kTraceBlock) k_trace(const TraceArgs a)
         while (need != 0ull && !(exhausted && pool_next == pool_end)) {
             if (pool_next == pool_end) {
                 unsigned int g = 0;
-                if (lane == 0) g = atomicAdd(a.work_counter, (unsigned int)a.chunk_items);
+                // Chunks shrink towards the end of the work (down to a floor that keeps the hand-out cheap next to the sweep) so that the waves run out of items
+                // at nearly the same time: with full-size chunks to the last, a wave can start a whole chunk
+                // (some twenty trips) just before the counter runs dry while its neighbours go idle.  What is left
+                // is estimated from this wave's previous reservation and one chunk per resident wave since.
+                uint32_t take = (uint32_t)a.chunk_items;
+                {
+                    const uint32_t seen = pool_end + a.resident_waves * take;
+                    const uint32_t left = a.total_items > seen ? a.total_items - seen : 0u;
+                    const uint32_t fair = (left / (a.resident_waves * 2u)) & ~63u;
+                    if (fair < take) take = fair < a.min_chunk_items ? a.min_chunk_items : fair;
+                }
+                if (lane == 0) g = atomicAdd(a.work_counter, take);
                 g = __builtin_amdgcn_readfirstlane(g);
                 if (g >= a.total_items) { exhausted = true; break; }
                 pool_next = g; pool_base = g;
-                pool_end = (a.total_items - g < (uint32_t)a.chunk_items) ? a.total_items : g + (uint32_t)a.chunk_items;
+                pool_end = (a.total_items - g < take) ? a.total_items : g + take;
                 // Generate the camera rays of the whole chunk now, all lanes busy, into this wave's staging
                 // rows in HBM; handing an item to a lane later is then eight loads.  (Generating on demand
                 // ran this code on every trip of the main loop for the third of the lanes that had finished.)
@@ -730,7 +745,7 @@ __global__ void __launch_bounds__(kTraceBlock) k_trace(const TraceArgs a)
         }
         float closest = FLT_MAX; int hit = -1;
         const unsigned long long live = __ballot(active);
-#ifdef RT_SECTION_TIMERS
+#ifdef RT_WAVE_TIMELINE
         was_sparse = __popcll(live) <= kFewPaths && live != 0ull;
 #endif
         if (__popcll(live) <= kFewPaths) closest_hit_few<kLds>(ray, a.tmin, sw, s_geom, live, lane, closest, hit);
@@ -750,7 +765,7 @@ __global__ void __launch_bounds__(kTraceBlock) k_trace(const TraceArgs a)
         }
     }
     T.flush(lane);
-#ifdef RT_SECTION_TIMERS
+#ifdef RT_WAVE_TIMELINE
     {
         const uint32_t w = blockIdx.x * (kTraceBlock / 64) + wave;
         if (lane == 0 && w < 8192u) { g_wave_times[0][w] = t_enter; const unsigned long long t_exit = __builtin_amdgcn_s_memrealtime(); g_wave_times[1][w] = t_dry ? t_dry : t_exit; g_wave_times[2][w] = t_exit; g_wave_times[3][w] = trips_dry; g_wave_times[4][w] = sparse_trips; g_wave_times[5][w] = sparse_ticks; }
@@ -942,9 +957,11 @@ extern "C" int rt_debug_section_ticks(unsigned long long* out8, int reset)
     if (reset) { unsigned long long z[8] = { 0 }; if (hipMemcpyToSymbol(HIP_SYMBOL(g_section_ticks), z, sizeof z) != hipSuccess) return -3; }
     return 0;
 }
-extern "C" int rt_debug_wave_times(unsigned long long* out_4x8192)
+#endif
+#ifdef RT_WAVE_TIMELINE
+extern "C" int rt_debug_wave_times(unsigned long long* out_6x8192)
 {
-    return hipMemcpyFromSymbol(out_4x8192, HIP_SYMBOL(g_wave_times), 6 * 8192 * sizeof(unsigned long long)) == hipSuccess ? 0 : -3;
+    return hipMemcpyFromSymbol(out_6x8192, HIP_SYMBOL(g_wave_times), 6 * 8192 * sizeof(unsigned long long)) == hipSuccess ? 0 : -3;
 }
 #endif
 
@@ -1264,6 +1281,8 @@ int rt_render_device(rt_context* ctx, const rt_params* p, float* d_rgb_mean, int
             const uint64_t floor_items = (32768ull / (uint64_t)ctx->n_pad + 63) / 64 * 64;     // tiny scenes: keep per-chunk work above the hand-out overhead
             if (chunk < floor_items) chunk = floor_items;
             a.chunk_items = (int)(chunk < 64 ? 64 : (chunk > (uint64_t)kChunkItems ? (uint64_t)kChunkItems : chunk));
+            a.resident_waves = (uint32_t)resident_waves;
+            { const uint64_t m = floor_items < 64 ? 64 : floor_items; a.min_chunk_items = (uint32_t)(m < (uint64_t)a.chunk_items ? m : (uint64_t)a.chunk_items); }
             uint64_t want_blocks = ((uint64_t)a.total_items + (uint64_t)a.chunk_items * (kTraceBlock / 64) - 1) / ((uint64_t)a.chunk_items * (kTraceBlock / 64));
             const uint64_t cap_blocks = (uint64_t)ctx->num_cu * bpc;
             const dim3 grid((unsigned)(want_blocks < cap_blocks ? want_blocks : cap_blocks)), block(kTraceBlock);

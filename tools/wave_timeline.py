@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""When do the persistent waves of k_trace stop?  Diagnostic build (make -C raytracing_amd/csrc prof): per wave the
+"""When do the persistent waves of k_trace stop?  Diagnostic build (make -C raytracing_amd/csrc prof, the -DRT_WAVE_TIMELINE library): per wave the
 s_memrealtime stamps at entry, at the moment it first found the work counter dry, and at exit (100 MHz ticks)."""
 import ctypes as C
 import os
@@ -8,19 +8,21 @@ import sys
 import numpy as np
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-os.environ["RT_AMD_LIB"] = os.path.join(ROOT, "tools", "librt_amd_prof.so")
+os.environ["RT_AMD_LIB"] = os.path.join(ROOT, "tools", "librt_amd_timeline.so")
 sys.path.insert(0, ROOT)
 import raytracing_amd as R
 
 spp = int(sys.argv[1]) if len(sys.argv) > 1 else 10
 depth = int(sys.argv[2]) if len(sys.argv) > 2 else 50
+ranks = int(sys.argv[3]) if len(sys.argv) > 3 else 1          # render only rank 0's share of an image split over this many GPUs
 rt = R.Renderer(0)
 rt.upload_scene(R.final_scene_table())
 rt.set_camera(R.final_camera(1200, 800))
 L = R.load_library()
 buf = np.zeros((6, 8192), dtype=np.uint64)
 for rep in range(2):
-    rgb, irgb, rays, ms = rt.render(rt.params(1200, 800, spp, seed=0, max_depth=depth))
+    band = next(b for b in (8, 4, 2, 1) if (800 // b) % ranks == 0)
+    rgb, irgb, rays, ms = rt.render(rt.params(1200, 800, spp, seed=0, max_depth=depth, band_rows=band, band_first=0, band_step=ranks))
 L.rt_debug_wave_times(buf.ctypes.data_as(C.POINTER(C.c_ulonglong)))
 live = buf[2] > 0
 t0 = buf[0][live].min()
