@@ -416,7 +416,10 @@ __device__ __forceinline__ void closest_hit(const RayD& ray, float tmin, const S
 // (sphere, t): HittableList::Hit's answer is the smallest accepted root over all spheres with ties going to the
 // lower index (hittablelist.cpp:21-29 with sphere.cpp:27-50: for one sphere the accepted root under a running
 // bound c is its first root above tmin, if below c), which does not depend on how the spheres are partitioned.
-constexpr int kFewPaths = 8;
+#ifndef RT_FEW_PATHS
+#define RT_FEW_PATHS 8
+#endif
+constexpr int kFewPaths = RT_FEW_PATHS;     // 2, 4 and 8 measure alike on the 1200x800 final scene at 10 spp, 16 and 24 are 4-6 % slower (tools/ab_few.sh)
 template <bool kLds>
 __device__ __forceinline__ void closest_hit_few(const RayD& ray, float tmin, const SweepScene& sw, const float4* s_geom,
                                                 unsigned long long live, int lane, float& closest, int& hit)
