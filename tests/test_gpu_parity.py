@@ -449,3 +449,41 @@ def test_random_scenes_match_oracle_in_all_modes(rt):
             assert rt.counters() == wcount, (case, n, mode)
             assert mismatch(rgb, want) == 0, (case, n, mode, mismatch(rgb, want))
             assert np.array_equal(irgb, wq), (case, n, mode)
+
+
+def test_tile_work_order_is_invisible_and_follows_scene_camera_and_rows(rt, monkeypatch):
+    """The order in which tiles are worked on (longest paths first, kept between calls) never shows in the image:
+    same bits as the image-order variant, and a new camera, scene or row selection is picked up by the next call."""
+    def fresh(scene, cam, p_kw, env=None):
+        if env:
+            monkeypatch.setenv("RT_AMD_TILE_ORDER", env)
+        r = R.Renderer(0)
+        monkeypatch.delenv("RT_AMD_TILE_ORDER", raising=False)
+        r.upload_scene(scene)
+        r.set_camera(cam)
+        out = r.render(r.params(**p_kw))[:3]
+        r.close()
+        return out
+
+    final, three = R.final_scene_table(), R.three_sphere_table(True)
+    cam_a, cam_b = R.final_camera(120, 72), R.Camera((3.0, 1.5, -6.0), (0.0, 0.5, 0.0), (0.0, 1.0, 0.0), 40.0, np.float32(120) / np.float32(72), 0.05, 6.0)
+    kw = dict(width=120, height=72, spp=3, seed=12)
+    rt.upload_scene(final)
+    rt.set_camera(cam_a)
+    first = rt.render(rt.params(**kw))[:3]
+    again = rt.render(rt.params(**kw))[:3]                       # second call reuses the stored order
+    ref = fresh(final, cam_a, kw, env="image")
+    for got in (first, again):
+        assert got[2] == ref[2] and mismatch(got[0], ref[0]) == 0 and np.array_equal(got[1], ref[1])
+    rt.set_camera(cam_b)                                         # new camera, same context
+    got = rt.render(rt.params(**kw))[:3]
+    ref = fresh(final, cam_b, kw, env="image")
+    assert got[2] == ref[2] and mismatch(got[0], ref[0]) == 0
+    rt.upload_scene(three)                                       # new scene, same camera
+    got = rt.render(rt.params(**kw))[:3]
+    ref = fresh(three, cam_b, kw, env="image")
+    assert got[2] == ref[2] and mismatch(got[0], ref[0]) == 0
+    kw_rows = dict(kw, band_rows=5, band_first=1, band_step=3)   # other rows, same scene and camera
+    got = rt.render(rt.params(**kw_rows))[:3]
+    ref = fresh(three, cam_b, kw_rows, env="image")
+    assert got[0].shape == ref[0].shape and got[2] == ref[2] and mismatch(got[0], ref[0]) == 0
