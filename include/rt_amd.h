@@ -141,6 +141,11 @@ int rt_scene_grid(uint64_t seed, int half_extent, int max_small, float *table9, 
 int64_t rt_format_ppm(const int32_t *irgb, int width, int height, char *buf, int64_t cap);
 /* Creates/truncates `path` and writes the P3 image. */
 int rt_write_ppm(const char *path, const int32_t *irgb, int width, int height);
+/* The same image as binary P6 ("P6\n{w} {h}\n255\n" + one byte per channel): a quarter of the bytes of the
+ * text form, for callers that do not need the reference's exact file.  Fails with RT_ERR_INVALID when a value
+ * is outside 0..255 (the reference's int(255.99*c) is not clamped, main.cpp:138-140; the text form keeps such
+ * values, a byte cannot). */
+int rt_write_ppm_binary(const char *path, const int32_t *irgb, int width, int height);
 /* The same text produced on the GPU from a device-resident quantised image (the d_irgb of
  * rt_render_device), so that the only host traffic is the finished text.  d_text: device buffer of `cap`
  * bytes; *bytes receives the length of the text.  When d_text is NULL or cap is too small nothing is

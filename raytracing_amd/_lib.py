@@ -14,7 +14,7 @@ LAMBERTIAN, METAL, DIELECTRIC = 0, 1, 2
 # every symbol include/rt_amd.h declares
 EXPORTS = ["rt_device_count", "rt_create", "rt_destroy", "rt_last_error", "rt_upload_scene", "rt_set_camera",
            "rt_owned_rows", "rt_owned_pixels", "rt_render_device", "rt_render_stats", "rt_render_counters", "rt_render",
-           "rt_scene_grid", "rt_format_ppm", "rt_write_ppm", "rt_encode_ppm_device", "rt_write_ppm_device", "rt_test_sphere_hit", "rt_test_scatter", "rt_test_get_ray",
+           "rt_scene_grid", "rt_format_ppm", "rt_write_ppm", "rt_write_ppm_binary", "rt_encode_ppm_device", "rt_write_ppm_device", "rt_test_sphere_hit", "rt_test_scatter", "rt_test_get_ray",
            "rt_test_philox"]
 
 
@@ -76,6 +76,7 @@ def load_library():
     L.rt_format_ppm.argtypes = [ip, C.c_int, C.c_int, C.c_char_p, C.c_int64]
     L.rt_format_ppm.restype = C.c_int64
     L.rt_write_ppm.argtypes = [C.c_char_p, ip, C.c_int, C.c_int]
+    L.rt_write_ppm_binary.argtypes = [C.c_char_p, ip, C.c_int, C.c_int]
     L.rt_encode_ppm_device.argtypes = [vp, vp, C.c_int, C.c_int, vp, C.c_int64, C.POINTER(C.c_int64), vp]
     L.rt_write_ppm_device.argtypes = [vp, C.c_char_p, vp, C.c_int, C.c_int, vp]
     L.rt_test_sphere_hit.argtypes = [vp, C.c_int, fp, fp, fp, fp, fp, fp, ip, fp, fp, fp]
@@ -301,5 +302,13 @@ def format_ppm(irgb):
 def write_ppm(path, irgb):
     a = _i32(irgb)
     rc = load_library().rt_write_ppm(os.fsencode(path), _ip(a.reshape(-1)), a.shape[1], a.shape[0])
+    if rc != 0:
+        raise RtError(rc, load_library().rt_last_error(None).decode())
+
+
+def write_ppm_binary(path, irgb):
+    """Binary P6 form of the same image (values must fit a byte)."""
+    a = _i32(irgb)
+    rc = load_library().rt_write_ppm_binary(os.fsencode(path), _ip(a.reshape(-1)), a.shape[1], a.shape[0])
     if rc != 0:
         raise RtError(rc, load_library().rt_last_error(None).decode())

@@ -203,6 +203,26 @@ int rt_write_ppm(const char* path, const int32_t* irgb, int width, int height)
     return w == (size_t)n ? RT_OK : fail(nullptr, RT_ERR_INVALID, "rt_write_ppm: short write to %s", path);
 }
 
+int rt_write_ppm_binary(const char* path, const int32_t* irgb, int width, int height)
+{
+    if (!path || !irgb || width <= 0 || height <= 0) return fail(nullptr, RT_ERR_INVALID, "rt_write_ppm_binary: bad argument");
+    char head[48];
+    const int hn = snprintf(head, sizeof head, "P6\n%d %d\n255\n", width, height);
+    const size_t n = (size_t)width * height * 3;
+    std::vector<unsigned char> buf((size_t)hn + n);
+    memcpy(buf.data(), head, hn);
+    for (size_t k = 0; k < n; ++k) {
+        const int32_t v = irgb[k];
+        if (v < 0 || v > 255) return fail(nullptr, RT_ERR_INVALID, "rt_write_ppm_binary: value %d at element %zu does not fit a byte (the P3 form writes it as text)", v, k);
+        buf[hn + k] = (unsigned char)v;
+    }
+    FILE* f = fopen(path, "wb");
+    if (!f) return fail(nullptr, RT_ERR_INVALID, "rt_write_ppm_binary: cannot open %s", path);
+    const size_t w = fwrite(buf.data(), 1, buf.size(), f);
+    const int closed = fclose(f);
+    return (w == buf.size() && closed == 0) ? RT_OK : fail(nullptr, RT_ERR_INVALID, "rt_write_ppm_binary: short write to %s", path);
+}
+
 int rt_encode_ppm_device(rt_context* ctx, const int32_t* d_irgb, int width, int height, char* d_text, int64_t cap, int64_t* bytes, void* stream)
 {
     if (!ctx) return fail(nullptr, RT_ERR_INVALID, "rt_encode_ppm_device: null context");

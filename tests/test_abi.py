@@ -4,6 +4,7 @@ import os
 import re
 
 import numpy as np
+import pytest
 
 import raytracing_amd as R
 from raytracing_amd import _lib
@@ -52,6 +53,20 @@ def test_ppm_bytes_match_reference_format():
     os.makedirs(os.path.dirname(path), exist_ok=True)
     R.write_ppm(path, irgb)
     assert open(path, "rb").read() == want.encode()
+    # larger random images, every value the quantiser can produce, against Python's own formatting
+    rng = np.random.default_rng(3)
+    for (w, h) in [(1, 1), (17, 9), (301, 77)]:
+        img = rng.integers(0, 256, size=(h, w, 3), dtype=np.int32)
+        img.reshape(-1)[rng.integers(0, img.size, size=min(8, img.size))] = [-1, 256, 1000, -2147483648, 2147483647, 99999, 10, 100][:min(8, img.size)]
+        text = f"P3\n{w} {h}\n255\n" + "".join(f"{p[0]} {p[1]} {p[2]}\n" for row in img for p in row)
+        assert R.format_ppm(img) == text.encode()
+    # binary P6 form: header + one byte per channel; values outside a byte are refused
+    img = rng.integers(0, 256, size=(9, 17, 3), dtype=np.int32)
+    R.write_ppm_binary(path, img)
+    assert open(path, "rb").read() == b"P6\n17 9\n255\n" + img.astype(np.uint8).tobytes()
+    img[2, 3, 1] = 256
+    with pytest.raises(R.RtError):
+        R.write_ppm_binary(path, img)
 
 
 def test_null_and_invalid_arguments_are_reported_not_fatal():
