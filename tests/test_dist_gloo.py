@@ -51,7 +51,7 @@ def _worker(rank, world, port, band, q):
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("band", [4, 8])
+@pytest.mark.parametrize("band", [1, 4, 8])
 def test_two_rank_gather_reassembles_image(band):
     world = 2
     ctx = mp.get_context("spawn")
@@ -70,7 +70,7 @@ def test_two_rank_gather_reassembles_image(band):
 
 
 def test_band_layout_covers_every_row_once():
-    for height, band, world in [(800, 8, 1), (800, 8, 2), (800, 8, 8), (2160, 8, 8), (27, 4, 2), (50, 16, 4), (5, 8, 8)]:
+    for height, band, world in [(800, 8, 1), (800, 8, 2), (800, 8, 8), (800, 1, 8), (800, 1, 4), (801, 1, 8), (2160, 8, 8), (27, 4, 2), (50, 16, 4), (5, 8, 8)]:
         seen = np.zeros(height, dtype=int)
         for r in range(world):
             for y0, y1 in rdist.owned_bands(height, band, r, world):
