@@ -129,7 +129,7 @@ def main():
     ap.add_argument("--band-rows", type=int, default=0, help="rows per band (0 = 8 on one GPU, 1 on several)")
     ap.add_argument("--seed", type=int, default=0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--mode", default="megakernel", choices=["megakernel", "wavefront", "pixel"])
+    ap.add_argument("--mode", default="megakernel", choices=["megakernel", "wavefront", "pixel", "bvh"])
     ap.add_argument("--rehearse-on-one-gpu", action="store_true",
                     help="debug: all ranks share GPU 0 and gather over gloo (RCCL refuses two ranks on one device)")
     args = ap.parse_args()
@@ -182,7 +182,7 @@ def main():
         # cheap and expensive rows (tools/rank_share.py: the slowest of 8 ranks is 1.5 % above the mean with 1-row bands, 4 % with
         # 4-row bands, 11 % with 8-row bands)
         band = 8 if world == 1 else 1
-    mode = {"megakernel": R.MODE_MEGAKERNEL, "wavefront": R.MODE_WAVEFRONT, "pixel": R.MODE_PIXEL}[args.mode]
+    mode = {"megakernel": R.MODE_MEGAKERNEL, "wavefront": R.MODE_WAVEFRONT, "pixel": R.MODE_PIXEL, "bvh": R.MODE_BVH}[args.mode]
     p = rt.params(width, height, spp, seed=args.seed, band_rows=band, band_first=rank, band_step=world, mode=mode)
     pad = rdist.max_owned_rows(height, band, world)
     out = torch.zeros((pad, width, 3), dtype=torch.int32, device=dev)
@@ -247,7 +247,7 @@ def main():
             "roofline": {"bound": "valu", "achieved": achieved, "peak": PEAK_FP32_VALU_TFLOPS, "unit": "TFLOP/s",
                          "frac": achieved / PEAK_FP32_VALU_TFLOPS,
                          "traffic": (HBM_BYTES_PER_RAY_PMC * my_rays) if args.mode == "megakernel" else None, "traffic_unit": "bytes per step of this rank (PMC-derived constant per ray)",
-                         "kernel": {"megakernel": "k_trace", "wavefront": "k_wf_intersect + k_wf_shade", "pixel": "k_render_mega"}[args.mode], "flop_per_ray": flop_per_ray,
+                         "kernel": {"megakernel": "k_trace", "wavefront": "k_wf_intersect + k_wf_shade", "pixel": "k_render_mega", "bvh": "k_trace (hierarchy walk)"}[args.mode], "flop_per_ray": flop_per_ray,
                          "note": "FP32 vector-ALU bound (HBM traffic and MFMA are not on this path); algorithmic flops = rays x (18 x spheres + 150)"},
         }
         line.update(cpu_lines)

@@ -41,7 +41,10 @@ enum rt_mode {
     RT_MODE_WAVEFRONT = 1,    /* a pool of path slots and ray queues in HBM: one intersect and one shade
                                  kernel per bounce, surviving slots compacted with wave ballot/prefix counts;
                                  the host reads the live count every 8 bounces, so the call synchronises */
-    RT_MODE_PIXEL = 2         /* plain kernel: one lane per pixel, literal per-sphere test, scene in LDS */
+    RT_MODE_PIXEL = 2,        /* plain kernel: one lane per pixel, literal per-sphere test, scene in LDS */
+    RT_MODE_BVH = 3           /* the megakernel with the brute-force sweep of hittablelist.cpp:21-29 replaced by a walk
+                                 through a hierarchy of sphere-centre boxes built at upload; same (sphere, t) for every
+                                 ray, hence the same image.  Not the path the headline benchmark measures */
 };
 
 /* The eight public fields of Camera (camera.h:13-21), copied one to one. */

@@ -8,7 +8,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 # RT_AMD_LIB selects another build of the same ABI (diagnostic builds under tools/)
 LIB_PATH = os.environ.get("RT_AMD_LIB") or os.path.join(_HERE, "librt_amd.so")
 
-MODE_MEGAKERNEL, MODE_WAVEFRONT, MODE_PIXEL = 0, 1, 2
+MODE_MEGAKERNEL, MODE_WAVEFRONT, MODE_PIXEL, MODE_BVH = 0, 1, 2, 3
 LAMBERTIAN, METAL, DIELECTRIC = 0, 1, 2
 
 # every symbol include/rt_amd.h declares

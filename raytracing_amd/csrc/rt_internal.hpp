@@ -37,7 +37,9 @@ struct rt_context {
     uint32_t wf_P = 0; float* wf_ray = nullptr; uint32_t* wf_pixsmp = nullptr; int* wf_depth = nullptr; float* wf_hit_t = nullptr; int* wf_hit_idx = nullptr;
     uint16_t* wf_stacks = nullptr; uint32_t* wf_q[2] = { nullptr, nullptr }; uint32_t* wf_n = nullptr;
     int wf_blocks_per_cu[4] = { 0, 0, 0, 0 };
-    int num_cu = 0; int trace_blocks_per_cu[5] = { 0, 0, 0, 0, 0 };
+    int num_cu = 0; int trace_blocks_per_cu[7] = { 0, 0, 0, 0, 0, 0, 0 };
+    // sphere hierarchy of RT_MODE_BVH (rt_bvh.hpp), rebuilt with every scene upload
+    float4* d_bvh_nodes = nullptr; uint32_t* d_bvh_leaf = nullptr; uint32_t* d_bvh_big = nullptr; int bvh_n_big = 0, bvh_depth = 0, bvh_nodes = 0;
     bool have_camera = false; CameraD cam{};
     unsigned long long* d_rays = nullptr;      // [0] closest-hit queries, [1] those that hit nothing
     uint64_t last_samples = 0;                // primary rays of the last render (owned pixels x spp)
@@ -67,7 +69,7 @@ inline bool params_ok(const rt_params* p)
 {
     return p && p->width > 0 && p->height > 0 && p->spp > 0 && p->max_depth >= 0 && p->max_depth <= RT_MAX_DEPTH &&
            p->band_rows > 0 && p->band_first >= 0 && p->band_step > 0 &&
-           (p->mode == RT_MODE_MEGAKERNEL || p->mode == RT_MODE_WAVEFRONT || p->mode == RT_MODE_PIXEL);
+           (p->mode == RT_MODE_MEGAKERNEL || p->mode == RT_MODE_WAVEFRONT || p->mode == RT_MODE_PIXEL || p->mode == RT_MODE_BVH);
 }
 
 namespace {

@@ -9,6 +9,7 @@
 #include <type_traits>
 #include <vector>
 #include "rt_internal.hpp"
+#include "rt_bvh.hpp"
 
 // ============================================================================ device data layout
 // Scene records in HBM (built once per upload) and, for the megakernel, mirrored into LDS:
@@ -181,6 +182,11 @@ __global__ void __launch_bounds__(kBlock) k_render_mega(const RenderArgs a)
 //            unfused arithmetic (sphere.cpp:15-52); the accepted root of each and the running minimum
 //            follow hittablelist.cpp:13-31, so the chosen sphere and t are bit-identical.
 // A wave left with only a few live paths (the end of a launch) switches to closest_hit_few.
+// Device view of the sphere hierarchy (rt_bvh.hpp) for RT_MODE_BVH.
+struct BvhScene {
+    const float4* nodes; const uint32_t* leaf_index; const uint32_t* big; int n_big;
+    const float4* geom;
+};
 struct TraceArgs {
     const float4* prec;      // plane-filter records (cx, cz, R_i = r^2 + slack_i, 0), same padding as frec
     float plane_s0, plane_rmin;   // plane filter: constant part of the per-ray slack, smallest R_i
@@ -201,6 +207,7 @@ struct TraceArgs {
     unsigned int* work_counter;
     float* staging;                       // per wave: kStagingRows rows (o, d, pixel, sample, sample-buffer slot) of kChunkItems pre-generated camera rays
     const uint32_t* tile_order;           // work order of the tiles (see decode_item); may be null
+    BvhScene bvh;                         // RT_MODE_BVH only
     uint16_t* stacks; uint32_t stack_stride;   // hit-index stacks in HBM: entry k of lane g at stacks[k * stack_stride + g]
 };
 
@@ -464,6 +471,75 @@ __device__ __forceinline__ void closest_hit_few(const RayD& ray, float tmin, con
     }
 }
 
+// ============================================================================ closest hit through the sphere hierarchy
+// RT_MODE_BVH: the same closest hit as the brute-force sweep, found by walking the hierarchy of rt_bvh.hpp per lane.
+// Every sphere that is tested goes through the reference's own arithmetic (sphere.cpp:15-52); the hierarchy only
+// decides which spheres can be skipped, so the box test has to be conservative against that arithmetic:
+//   * the reference reports a hit when its float discriminant b^2 - a c is positive.  With u = 2^-24 the computed
+//     value is off by less than 16 u a (2 |o - c|^2 + r^2), so the line may pass up to sqrt(r^2 + 32 u |o - c|^2 +
+//     16 u r^2) from the centre.  A node's centre box is therefore inflated by sqrt(rmax^2 + 64 u (D^2 + rmax^2)),
+//     D = distance from the ray origin to the farthest corner of the box (>= |o - c| for every sphere below);
+//   * the slab test's own rounding is covered by a further relative 1e-5 and an absolute 1e-6 (1 + |o| + |box|).
+// The closest hit over a set of spheres is the smallest accepted root, equal roots going to the lower index
+// (hittablelist.cpp:21-29 keeps the first of equal ones and visits in index order); spheres are met here in
+// tree order, so the tie is resolved explicitly.
+constexpr float kBvhSlack = 64.0f * 5.9604645e-08f;
+
+template <bool kLds>
+__device__ __forceinline__ void bvh_test_sphere(const RayD& ray, float qa, float tmin, const BvhScene& bv, const float4* s_geom, int k, float& closest, int& hit)
+{
+    const float4 g = kLds ? s_geom[k] : bv.geom[k];
+    const V3 oc = ray.o - mk(g.x, g.y, g.z);
+    const float b = dot(oc, ray.d);
+    const float cc = dot(oc, oc) - g.w;
+    const float desc = b * b - qa * cc;
+    if (desc > 0.0f) {
+        const float sq = sqrtf(desc);
+        float temp = (-b - sq) / qa;
+        if (!(temp > tmin)) temp = (-b + sq) / qa;          // the first root above tmin is the one a running bound can accept
+        if (temp > tmin && (temp < closest || (temp == closest && k < hit))) { closest = temp; hit = k; }
+    }
+}
+
+// pending: this lane's column of kBvhStack LDS words (entry e at pending[e * 64]).
+template <bool kLds>
+__device__ __forceinline__ void closest_hit_bvh(const RayD& ray, float tmin, const BvhScene& bv, const float4* s_geom, uint32_t* pending, float& closest, int& hit)
+{
+    const float qa = dot(ray.d, ray.d);
+    for (int j = 0; j < bv.n_big; ++j) bvh_test_sphere<kLds>(ray, qa, tmin, bv, s_geom, (int)bv.big[j], closest, hit);
+    const float ix = 1.0f / ray.d.x, iy = 1.0f / ray.d.y, iz = 1.0f / ray.d.z;
+    const float omag = fabsf(ray.o.x) + fabsf(ray.o.y) + fabsf(ray.o.z);
+    const float t_low = tmin < 0.0f ? -FLT_MAX : 0.0f;
+    int sp = 0; uint32_t node = 0u;
+    for (;;) {
+        const float4 A = bv.nodes[2u * node], B = bv.nodes[2u * node + 1u];
+        const float fx = fmaxf(fabsf(ray.o.x - A.x), fabsf(ray.o.x - B.x));
+        const float fy = fmaxf(fabsf(ray.o.y - A.y), fabsf(ray.o.y - B.y));
+        const float fz = fmaxf(fabsf(ray.o.z - A.z), fabsf(ray.o.z - B.z));
+        const float far2 = fmaf(fx, fx, fmaf(fy, fy, fz * fz));
+        const float r2 = A.w * A.w;
+        float pad = sqrtf(fmaf(kBvhSlack, far2 + r2, r2));
+        pad = fmaf(pad, 1.00001f, 1e-6f * (1.0f + omag + fabsf(A.x) + fabsf(A.y) + fabsf(A.z) + fabsf(B.x) + fabsf(B.y) + fabsf(B.z)));
+        const float ax = (A.x - pad - ray.o.x) * ix, bx = (B.x + pad - ray.o.x) * ix;
+        const float ay = (A.y - pad - ray.o.y) * iy, by = (B.y + pad - ray.o.y) * iy;
+        const float az = (A.z - pad - ray.o.z) * iz, bz = (B.z + pad - ray.o.z) * iz;
+        const float t0 = fmaxf(fmaxf(fminf(ax, bx), fminf(ay, by)), fminf(az, bz));
+        const float t1 = fminf(fminf(fmaxf(ax, bx), fmaxf(ay, by)), fmaxf(az, bz));
+        if (t0 <= t1 && t1 >= t_low && t0 <= closest) {            // false for a NaN ray: it hits nothing in the reference either
+            const int link = __float_as_int(B.w);
+            if (link >= 0) {
+                pending[sp * 64] = (uint32_t)link + 1u; ++sp;
+                node = (uint32_t)link;
+                continue;
+            }
+            const int code = -(link + 1), first = code >> 3, count = (code & 7) + 1;
+            for (int q = 0; q < count; ++q) bvh_test_sphere<kLds>(ray, qa, tmin, bv, s_geom, (int)bv.leaf_index[first + q], closest, hit);
+        }
+        if (sp == 0) break;
+        --sp; node = pending[sp * 64];
+    }
+}
+
 // ============================================================================ shading step of Color()
 // One level of the recursion main.cpp:13-39 for a ray whose closest hit is known.  Returns true when the
 // path has ended (sample = its radiance); otherwise ray/depth are advanced and the hit index is pushed on
@@ -618,7 +694,7 @@ __global__ void __launch_bounds__(1024) k_tile_order(const TileArgs a)
     }
 }
 
-template <bool kLds, bool kPlane, bool kRecLds = false>
+template <bool kLds, bool kPlane, bool kRecLds = false, bool kBvh = false>
 __global__ void __launch_bounds__(kTraceBlock) k_trace(const TraceArgs a)
 {
     extern __shared__ float4 smem[];
@@ -632,10 +708,12 @@ __global__ void __launch_bounds__(kTraceBlock) k_trace(const TraceArgs a)
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     // Per-lane filter masks of one super-chunk: word w of lane l at mask_words[w * 64] (lanes contiguous).
     char* lds_after_scene = reinterpret_cast<char*>(smem) + (kLds ? (size_t)a.n * kLdsBytesPerSphere : 0);
-    uint32_t* mask_words = reinterpret_cast<uint32_t*>(lds_after_scene) + (size_t)wave * kSuperChunkWords * 64 + lane;
+    // (In RT_MODE_BVH the same area holds each lane's stack of pending nodes instead.)
+    constexpr int kWordsPerLane = kBvh ? kBvhStack : kSuperChunkWords;
+    uint32_t* mask_words = reinterpret_cast<uint32_t*>(lds_after_scene) + (size_t)wave * kWordsPerLane * 64 + lane;
     // Measurement variant (kRecLds): plane-filter records mirrored in LDS and read by broadcast ds_read_b128
     // instead of by scalar load.
-    float4* s_prec = reinterpret_cast<float4*>(lds_after_scene + (size_t)(kTraceBlock / 64) * kSuperChunkWords * 64 * sizeof(uint32_t));
+    float4* s_prec = reinterpret_cast<float4*>(lds_after_scene + (size_t)(kTraceBlock / 64) * kWordsPerLane * 64 * sizeof(uint32_t));
     if (kRecLds) { for (int i = threadIdx.x; i < a.n_pad; i += kTraceBlock) s_prec[i] = a.prec[i]; }
     __syncthreads();
     // The recursion's attenuation chain is replayed innermost-first when a path reaches the sky, so
@@ -751,7 +829,8 @@ __global__ void __launch_bounds__(kTraceBlock) k_trace(const TraceArgs a)
 #ifdef RT_WAVE_TIMELINE
         was_sparse = __popcll(live) <= kFewPaths && live != 0ull;
 #endif
-        if (__popcll(live) <= kFewPaths) closest_hit_few<kLds>(ray, a.tmin, sw, s_geom, live, lane, closest, hit);
+        if (kBvh) { if (active) closest_hit_bvh<kLds>(ray, a.tmin, a.bvh, s_geom, mask_words, closest, hit); }
+        else if (__popcll(live) <= kFewPaths) closest_hit_few<kLds>(ray, a.tmin, sw, s_geom, live, lane, closest, hit);
         else if (active) closest_hit<kLds, kPlane, kRecLds>(ray, a.tmin, sw, s_geom, s_prec, mask_words, closest, hit, T);
         if (active) {
             T.mark(4);
@@ -1012,6 +1091,7 @@ void rt_destroy(rt_context* ctx)
     (void)hipSetDevice(ctx->device);
     if (ctx->pending) (void)hipStreamSynchronize(ctx->last_stream);
     (void)hipFree(ctx->d_geom); (void)hipFree(ctx->d_mat); (void)hipFree(ctx->d_aux); (void)hipFree(ctx->d_rays); (void)hipFree(ctx->d_ppm_scratch); (void)hipFree(ctx->d_out_rgb); (void)hipFree(ctx->d_out_irgb);
+    (void)hipFree(ctx->d_bvh_nodes); (void)hipFree(ctx->d_bvh_leaf); (void)hipFree(ctx->d_bvh_big);
     (void)hipFree(ctx->d_frec); (void)hipFree(ctx->d_prec); (void)hipFree(ctx->d_samples); (void)hipFree(ctx->d_accum); (void)hipFree(ctx->d_work); (void)hipFree(ctx->d_stacks); (void)hipFree(ctx->d_staging); (void)hipFree(ctx->d_tile_cls); (void)hipFree(ctx->d_tile_order);
     (void)hipFree(ctx->wf_ray); (void)hipFree(ctx->wf_pixsmp); (void)hipFree(ctx->wf_depth); (void)hipFree(ctx->wf_hit_t); (void)hipFree(ctx->wf_hit_idx);
     (void)hipFree(ctx->wf_stacks); (void)hipFree(ctx->wf_q[0]); (void)hipFree(ctx->wf_q[1]); (void)hipFree(ctx->wf_n);
@@ -1086,6 +1166,19 @@ int rt_upload_scene(rt_context* ctx, int n, const float* cx, const float* cy, co
     HIP_TRY(ctx, hipMemcpy(ctx->d_geom, geom.data(), sizeof(float4) * n, hipMemcpyHostToDevice));
     HIP_TRY(ctx, hipMemcpy(ctx->d_mat, mat.data(), sizeof(float4) * n, hipMemcpyHostToDevice));
     HIP_TRY(ctx, hipMemcpy(ctx->d_aux, aux.data(), sizeof(Aux) * n, hipMemcpyHostToDevice));
+    {
+        BvhHost tree;
+        if (!build_bvh(n, cx, cy, cz, radius, &tree)) return fail(ctx, RT_ERR_TOO_LARGE, "rt_upload_scene: sphere hierarchy deeper than %d levels", kBvhStack - 2);
+        (void)hipFree(ctx->d_bvh_nodes); (void)hipFree(ctx->d_bvh_leaf); (void)hipFree(ctx->d_bvh_big);
+        ctx->d_bvh_nodes = nullptr; ctx->d_bvh_leaf = nullptr; ctx->d_bvh_big = nullptr;
+        HIP_TRY(ctx, hipMalloc(&ctx->d_bvh_nodes, sizeof(float4) * tree.nodes.size()));
+        HIP_TRY(ctx, hipMemcpy(ctx->d_bvh_nodes, tree.nodes.data(), sizeof(float4) * tree.nodes.size(), hipMemcpyHostToDevice));
+        HIP_TRY(ctx, hipMalloc(&ctx->d_bvh_leaf, sizeof(uint32_t) * tree.leaf_index.size()));
+        HIP_TRY(ctx, hipMemcpy(ctx->d_bvh_leaf, tree.leaf_index.data(), sizeof(uint32_t) * tree.leaf_index.size(), hipMemcpyHostToDevice));
+        HIP_TRY(ctx, hipMalloc(&ctx->d_bvh_big, sizeof(uint32_t) * (tree.big.size() + 1)));
+        if (!tree.big.empty()) HIP_TRY(ctx, hipMemcpy(ctx->d_bvh_big, tree.big.data(), sizeof(uint32_t) * tree.big.size(), hipMemcpyHostToDevice));
+        ctx->bvh_n_big = (int)tree.big.size(); ctx->bvh_depth = tree.depth; ctx->bvh_nodes = tree.node_count();
+    }
     ctx->n = n; ++ctx->scene_version;
     return RT_OK;
 }
@@ -1157,12 +1250,14 @@ int rt_render_device(rt_context* ctx, const rt_params* p, float* d_rgb_mean, int
         }
         const bool lds = ctx->n <= kMaxLdsSpheres;
         const bool plane = ctx->plane_filter;
-        const bool reclds = ctx->records_in_lds && lds && plane && ctx->n_pad <= 2048;
-        const size_t shmem = (lds ? (size_t)ctx->n * kLdsBytesPerSphere : 0) + (size_t)(kTraceBlock / 64) * kSuperChunkWords * 64 * sizeof(uint32_t) + (reclds ? (size_t)ctx->n_pad * sizeof(float4) : 0);
-        int& bpc = ctx->trace_blocks_per_cu[reclds ? 4 : (lds ? 1 : 0) + (plane ? 2 : 0)];
+        const bool bvh = p->mode == RT_MODE_BVH;
+        const bool reclds = !bvh && ctx->records_in_lds && lds && plane && ctx->n_pad <= 2048;
+        const size_t shmem = (lds ? (size_t)ctx->n * kLdsBytesPerSphere : 0) + (size_t)(kTraceBlock / 64) * (bvh ? kBvhStack : kSuperChunkWords) * 64 * sizeof(uint32_t) + (reclds ? (size_t)ctx->n_pad * sizeof(float4) : 0);
+        int& bpc = ctx->trace_blocks_per_cu[bvh ? (lds ? 6 : 5) : reclds ? 4 : (lds ? 1 : 0) + (plane ? 2 : 0)];
         if (bpc == 0) {
             int nb = 0;
-            auto kern = reclds ? k_trace<true, true, true> : lds ? (plane ? k_trace<true, true> : k_trace<true, false>) : (plane ? k_trace<false, true> : k_trace<false, false>);
+            auto kern = bvh ? (lds ? k_trace<true, true, false, true> : k_trace<false, true, false, true>)
+                      : reclds ? k_trace<true, true, true> : lds ? (plane ? k_trace<true, true> : k_trace<true, false>) : (plane ? k_trace<false, true> : k_trace<false, false>);
             hipError_t e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, kern, kTraceBlock, shmem);
             if (e != hipSuccess || nb <= 0) nb = 1;
             bpc = nb;
@@ -1177,7 +1272,7 @@ int rt_render_device(rt_context* ctx, const rt_params* p, float* d_rgb_mean, int
             ctx->stacks_lanes = lanes;
         }
         const uint32_t n_tiles = (uint32_t)(Q / 64);
-        const bool ordered = ctx->tile_ordering && p->mode == RT_MODE_MEGAKERNEL;
+        const bool ordered = ctx->tile_ordering && (p->mode == RT_MODE_MEGAKERNEL || bvh);
         if (ordered) {
             if (ctx->tile_cap < n_tiles) {
                 HIP_TRY(ctx, hipStreamSynchronize(st));
@@ -1277,6 +1372,7 @@ int rt_render_device(rt_context* ctx, const rt_params* p, float* d_rgb_mean, int
             a.samples = ctx->d_samples; a.ray_counter = ctx->d_rays; a.work_counter = ctx->d_work;
             a.stacks = ctx->d_stacks; a.stack_stride = (uint32_t)ctx->stacks_lanes; a.staging = ctx->d_staging;
             a.tile_order = ordered ? ctx->d_tile_order : nullptr;
+            a.bvh.nodes = ctx->d_bvh_nodes; a.bvh.leaf_index = ctx->d_bvh_leaf; a.bvh.big = ctx->d_bvh_big; a.bvh.n_big = ctx->bvh_n_big; a.bvh.geom = ctx->d_geom;
             HIP_TRY(ctx, hipMemsetAsync(ctx->d_work, 0, sizeof(unsigned int), st));
             // small jobs take smaller chunks so that every resident wave gets several (tail balance)
             const uint64_t resident_waves = (uint64_t)ctx->num_cu * bpc * (kTraceBlock / 64);
@@ -1289,7 +1385,9 @@ int rt_render_device(rt_context* ctx, const rt_params* p, float* d_rgb_mean, int
             uint64_t want_blocks = ((uint64_t)a.total_items + (uint64_t)a.chunk_items * (kTraceBlock / 64) - 1) / ((uint64_t)a.chunk_items * (kTraceBlock / 64));
             const uint64_t cap_blocks = (uint64_t)ctx->num_cu * bpc;
             const dim3 grid((unsigned)(want_blocks < cap_blocks ? want_blocks : cap_blocks)), block(kTraceBlock);
-            if (reclds) hipLaunchKernelGGL((k_trace<true, true, true>), grid, block, shmem, st, a);
+            if (bvh && lds) hipLaunchKernelGGL((k_trace<true, true, false, true>), grid, block, shmem, st, a);
+            else if (bvh) hipLaunchKernelGGL((k_trace<false, true, false, true>), grid, block, shmem, st, a);
+            else if (reclds) hipLaunchKernelGGL((k_trace<true, true, true>), grid, block, shmem, st, a);
             else if (lds && plane) hipLaunchKernelGGL((k_trace<true, true>), grid, block, shmem, st, a);
             else if (lds) hipLaunchKernelGGL((k_trace<true, false>), grid, block, shmem, st, a);
             else if (plane) hipLaunchKernelGGL((k_trace<false, true>), grid, block, shmem, st, a);

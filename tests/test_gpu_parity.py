@@ -132,7 +132,7 @@ def _setup(rt, m):
         rt.set_camera(R.three_camera(m["nx"], m["ny"]))
 
 
-@pytest.mark.parametrize("mode", [R.MODE_MEGAKERNEL, R.MODE_WAVEFRONT, R.MODE_PIXEL])
+@pytest.mark.parametrize("mode", [R.MODE_MEGAKERNEL, R.MODE_WAVEFRONT, R.MODE_PIXEL, R.MODE_BVH])
 @pytest.mark.parametrize("name", ["philox_final_96x64x4", "philox_final_40x30x16_ap0",
                                   "philox_three_hollow_80x45x8", "philox_three_64x36x32"])
 def test_render_is_bit_identical_to_reference_image(rt, name, mode):
@@ -229,6 +229,9 @@ def test_full_size_properties(rt):
     # the wavefront organisation of the same loop: same image, same ray count
     w, iw, rays_w, _ = rt.render(rt.params(1200, 800, 10, seed=0, mode=R.MODE_WAVEFRONT))
     assert rays_w == rays_a and np.array_equal(w.view(np.uint32), a.view(np.uint32)) and np.array_equal(iw, ia)
+    # and the hierarchy walk in place of the brute-force sweep
+    h, ih, rays_h, _ = rt.render(rt.params(1200, 800, 10, seed=0, mode=R.MODE_BVH))
+    assert rays_h == rays_a and np.array_equal(h.view(np.uint32), a.view(np.uint32)) and np.array_equal(ih, ia)
 
 
 def test_stress_scene_rows_match_oracle(rt):
@@ -244,6 +247,13 @@ def test_stress_scene_rows_match_oracle(rt):
     rgb, irgb, rays, _ = rt.render(p)
     want, wq, wrays = O.render(scene, ocam, 1920, 1080, 1, O.usrc_philox(4), 1080 - 702, 1080 - 700, fast=False)
     assert rays == wrays and same(rgb, want) and np.array_equal(irgb, wq)
+    # the hierarchy walk on the same rows, and on a larger part of the image against the brute-force kernel
+    p_bvh = rt.params(1920, 1080, 1, seed=4, band_rows=2, band_first=350, band_step=10000, mode=R.MODE_BVH)
+    rgb_b, irgb_b, rays_b, _ = rt.render(p_bvh)
+    assert rays_b == wrays and same(rgb_b, want) and np.array_equal(irgb_b, wq)
+    brute = rt.render(rt.params(1920, 1080, 2, seed=9, band_rows=40, band_first=3, band_step=9))
+    walk = rt.render(rt.params(1920, 1080, 2, seed=9, band_rows=40, band_first=3, band_step=9, mode=R.MODE_BVH))
+    assert brute[2] == walk[2] and mismatch(brute[0], walk[0]) == 0 and np.array_equal(brute[1], walk[1])
     # a mid-size scene whose count is not a multiple of the filter's 32-sphere chunk
     table = R.scene_grid(7, 20, 10 ** 6)
     assert len(table) % 32 != 0 and len(table) > 1536
@@ -252,8 +262,8 @@ def test_stress_scene_rows_match_oracle(rt):
     rgb, irgb, rays, _ = rt.render(rt.params(96, 64, 2, seed=8))
     want, wq, wrays = O.render(O.SceneArrays.from_table(table), O.final_camera(96, 64), 96, 64, 2, O.usrc_philox(8))
     assert rays == wrays and same(rgb, want) and np.array_equal(irgb, wq)
-    both = [rt.render(rt.params(96, 64, 2, seed=8, mode=m))[0] for m in (R.MODE_MEGAKERNEL, R.MODE_PIXEL, R.MODE_WAVEFRONT)]
-    assert same(both[0], both[1]) and same(both[0], both[2])
+    both = [rt.render(rt.params(96, 64, 2, seed=8, mode=m))[0] for m in (R.MODE_MEGAKERNEL, R.MODE_PIXEL, R.MODE_WAVEFRONT, R.MODE_BVH)]
+    assert same(both[0], both[1]) and same(both[0], both[2]) and same(both[0], both[3])
 
 
 def test_filter_variants_agree(rt, monkeypatch):
@@ -314,7 +324,7 @@ def test_depth_cap_and_second_context(rt):
         for cap in (1, 3, 7):
             O.lib().orc_set_max_depth(cap)
             want, wq, wrays = O.render(scene, ocam, 48, 27, 6, O.usrc_philox(21))
-            for mode in (R.MODE_MEGAKERNEL, R.MODE_WAVEFRONT, R.MODE_PIXEL):
+            for mode in (R.MODE_MEGAKERNEL, R.MODE_WAVEFRONT, R.MODE_PIXEL, R.MODE_BVH):
                 rgb, irgb, rays, _ = rt.render(rt.params(48, 27, 6, seed=21, max_depth=cap, mode=mode))
                 assert rays == wrays and same(rgb, want) and np.array_equal(irgb, wq), (cap, mode)
     finally:
@@ -443,7 +453,7 @@ def test_random_scenes_match_oracle_in_all_modes(rt):
         rt.set_camera(pod)
         seed = 1000 + case
         want, wq, wrays, wcount = O.render_counted(O.SceneArrays.from_table(table), ocam, W, H, S, O.usrc_philox(seed))
-        for mode in (R.MODE_MEGAKERNEL, R.MODE_WAVEFRONT, R.MODE_PIXEL):
+        for mode in (R.MODE_MEGAKERNEL, R.MODE_WAVEFRONT, R.MODE_PIXEL, R.MODE_BVH):
             rgb, irgb, rays, _ = rt.render(rt.params(W, H, S, seed=seed, mode=mode))
             assert rays == wrays, (case, n, mode)
             assert rt.counters() == wcount, (case, n, mode)
