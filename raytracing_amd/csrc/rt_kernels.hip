@@ -475,15 +475,18 @@ __device__ __forceinline__ void closest_hit_few(const RayD& ray, float tmin, con
 // RT_MODE_BVH: the same closest hit as the brute-force sweep, found by walking the hierarchy of rt_bvh.hpp per lane.
 // Every sphere that is tested goes through the reference's own arithmetic (sphere.cpp:15-52); the hierarchy only
 // decides which spheres can be skipped, so the box test has to be conservative against that arithmetic:
-//   * the reference reports a hit when its float discriminant b^2 - a c is positive.  With u = 2^-24 the computed
-//     value is off by less than 16 u a (2 |o - c|^2 + r^2), so the line may pass up to sqrt(r^2 + 32 u |o - c|^2 +
-//     16 u r^2) from the centre.  A node's centre box is therefore inflated by sqrt(rmax^2 + 64 u (D^2 + rmax^2)),
-//     D = distance from the ray origin to the farthest corner of the box (>= |o - c| for every sphere below);
+//   * the reference reports a hit when its float discriminant b^2 - a c is positive.  With u = 2^-24, counting the
+//     roundings of sphere.cpp:17-25 (oc: u per component; b: 4 u |oc||d|, so b^2: 9 u a |oc|^2; oc.oc - r^2:
+//     5 u |oc|^2 + 2 u r^2; a: 3 u a; the product a c: a (9 u |oc|^2 + 6 u r^2); the difference: u a |oc|^2), the
+//     computed value is off by less than a (19 u |o - c|^2 + 6 u r^2), so the line may pass up to
+//     sqrt(r^2 + 19 u |o - c|^2 + 6 u r^2) from the centre.  A node's centre box is therefore inflated by
+//     sqrt(rmax^2 + 24 u (D^2 + rmax^2)), D = distance from the ray origin to the farthest corner of the box
+//     (>= |o - c| for every sphere below);
 //   * the slab test's own rounding is covered by a further relative 1e-5 and an absolute 1e-6 (1 + |o| + |box|).
 // The closest hit over a set of spheres is the smallest accepted root, equal roots going to the lower index
 // (hittablelist.cpp:21-29 keeps the first of equal ones and visits in index order); spheres are met here in
 // tree order, so the tie is resolved explicitly.
-constexpr float kBvhSlack = 64.0f * 5.9604645e-08f;
+constexpr float kBvhSlack = 24.0f * 5.9604645e-08f;
 
 template <bool kLds>
 __device__ __forceinline__ void bvh_test_sphere(const RayD& ray, float qa, float tmin, const BvhScene& bv, const float4* s_geom, int k, float& closest, int& hit)
@@ -501,7 +504,29 @@ __device__ __forceinline__ void bvh_test_sphere(const RayD& ray, float qa, float
     }
 }
 
-// pending: this lane's column of kBvhStack LDS words (entry e at pending[e * 64]).
+// Conservative ray / inflated-centre-box test of one node (see above).  Returns the entry parameter in t_in.
+__device__ __forceinline__ bool bvh_enter(const RayD& ray, float ix, float iy, float iz, float omag, float t_low, float closest,
+                                          const float4 A, const float4 B, float& t_in)
+{
+    const float fx = fmaxf(fabsf(ray.o.x - A.x), fabsf(ray.o.x - B.x));
+    const float fy = fmaxf(fabsf(ray.o.y - A.y), fabsf(ray.o.y - B.y));
+    const float fz = fmaxf(fabsf(ray.o.z - A.z), fabsf(ray.o.z - B.z));
+    const float far2 = fmaf(fx, fx, fmaf(fy, fy, fz * fz));
+    const float r2 = A.w * A.w;
+    float pad = sqrtf(fmaf(kBvhSlack, far2 + r2, r2));
+    pad = fmaf(pad, 1.00001f, 1e-6f * (1.0f + omag + fabsf(A.x) + fabsf(A.y) + fabsf(A.z) + fabsf(B.x) + fabsf(B.y) + fabsf(B.z)));
+    const float ax = (A.x - pad - ray.o.x) * ix, bx = (B.x + pad - ray.o.x) * ix;
+    const float ay = (A.y - pad - ray.o.y) * iy, by = (B.y + pad - ray.o.y) * iy;
+    const float az = (A.z - pad - ray.o.z) * iz, bz = (B.z + pad - ray.o.z) * iz;
+    const float t0 = fmaxf(fmaxf(fminf(ax, bx), fminf(ay, by)), fminf(az, bz));
+    const float t1 = fminf(fminf(fmaxf(ax, bx), fmaxf(ay, by)), fmaxf(az, bz));
+    t_in = t0;
+    return t0 <= t1 && t1 >= t_low && t0 <= closest;          // false for a NaN ray: it hits nothing in the reference either
+}
+
+// pending: this lane's column of kBvhStack LDS words (entry e at pending[e * 64]).  The walk handles the two
+// children of a node together: leaves among them are tested at once, of two inner children the nearer is entered
+// and the other one's child pair is left pending (it is re-examined against the then-current closest hit when popped).
 template <bool kLds>
 __device__ __forceinline__ void closest_hit_bvh(const RayD& ray, float tmin, const BvhScene& bv, const float4* s_geom, uint32_t* pending, float& closest, int& hit)
 {
@@ -510,33 +535,37 @@ __device__ __forceinline__ void closest_hit_bvh(const RayD& ray, float tmin, con
     const float ix = 1.0f / ray.d.x, iy = 1.0f / ray.d.y, iz = 1.0f / ray.d.z;
     const float omag = fabsf(ray.o.x) + fabsf(ray.o.y) + fabsf(ray.o.z);
     const float t_low = tmin < 0.0f ? -FLT_MAX : 0.0f;
-    int sp = 0; uint32_t node = 0u;
+    auto test_leaf = [&](int link) {
+        const int code = -(link + 1), first = code >> 3, count = (code & 7) + 1;
+        for (int q = 0; q < count; ++q) bvh_test_sphere<kLds>(ray, qa, tmin, bv, s_geom, (int)bv.leaf_index[first + q], closest, hit);
+    };
+    const int root_link = __float_as_int(bv.nodes[1].w);
+    if (root_link < 0) {                    // at most one leaf in the whole tree
+        float t_in;
+        if (bvh_enter(ray, ix, iy, iz, omag, t_low, closest, bv.nodes[0], bv.nodes[1], t_in)) test_leaf(root_link);
+        return;
+    }
+    int sp = 0; uint32_t pair = (uint32_t)root_link;
     for (;;) {
-        const float4 A = bv.nodes[2u * node], B = bv.nodes[2u * node + 1u];
-        const float fx = fmaxf(fabsf(ray.o.x - A.x), fabsf(ray.o.x - B.x));
-        const float fy = fmaxf(fabsf(ray.o.y - A.y), fabsf(ray.o.y - B.y));
-        const float fz = fmaxf(fabsf(ray.o.z - A.z), fabsf(ray.o.z - B.z));
-        const float far2 = fmaf(fx, fx, fmaf(fy, fy, fz * fz));
-        const float r2 = A.w * A.w;
-        float pad = sqrtf(fmaf(kBvhSlack, far2 + r2, r2));
-        pad = fmaf(pad, 1.00001f, 1e-6f * (1.0f + omag + fabsf(A.x) + fabsf(A.y) + fabsf(A.z) + fabsf(B.x) + fabsf(B.y) + fabsf(B.z)));
-        const float ax = (A.x - pad - ray.o.x) * ix, bx = (B.x + pad - ray.o.x) * ix;
-        const float ay = (A.y - pad - ray.o.y) * iy, by = (B.y + pad - ray.o.y) * iy;
-        const float az = (A.z - pad - ray.o.z) * iz, bz = (B.z + pad - ray.o.z) * iz;
-        const float t0 = fmaxf(fmaxf(fminf(ax, bx), fminf(ay, by)), fminf(az, bz));
-        const float t1 = fminf(fminf(fmaxf(ax, bx), fmaxf(ay, by)), fmaxf(az, bz));
-        if (t0 <= t1 && t1 >= t_low && t0 <= closest) {            // false for a NaN ray: it hits nothing in the reference either
-            const int link = __float_as_int(B.w);
-            if (link >= 0) {
-                pending[sp * 64] = (uint32_t)link + 1u; ++sp;
-                node = (uint32_t)link;
-                continue;
-            }
-            const int code = -(link + 1), first = code >> 3, count = (code & 7) + 1;
-            for (int q = 0; q < count; ++q) bvh_test_sphere<kLds>(ray, qa, tmin, bv, s_geom, (int)bv.leaf_index[first + q], closest, hit);
+        const float4 A0 = bv.nodes[2u * pair], B0 = bv.nodes[2u * pair + 1u], A1 = bv.nodes[2u * pair + 2u], B1 = bv.nodes[2u * pair + 3u];
+        float t_in0, t_in1;
+        bool in0 = bvh_enter(ray, ix, iy, iz, omag, t_low, closest, A0, B0, t_in0);
+        bool in1 = bvh_enter(ray, ix, iy, iz, omag, t_low, closest, A1, B1, t_in1);
+        const int link0 = __float_as_int(B0.w), link1 = __float_as_int(B1.w);
+        if (in0 && link0 < 0) { test_leaf(link0); in0 = false; }
+        if (in1 && link1 < 0) { test_leaf(link1); in1 = false; }
+        in0 = in0 && t_in0 <= closest;      // the leaves may have brought the closest hit nearer
+        in1 = in1 && t_in1 <= closest;
+        if (in0 && in1) {
+            const bool first0 = t_in0 <= t_in1;
+            pending[sp * 64] = (uint32_t)(first0 ? link1 : link0); ++sp;
+            pair = (uint32_t)(first0 ? link0 : link1);
+            continue;
         }
+        if (in0) { pair = (uint32_t)link0; continue; }
+        if (in1) { pair = (uint32_t)link1; continue; }
         if (sp == 0) break;
-        --sp; node = pending[sp * 64];
+        --sp; pair = pending[sp * 64];
     }
 }
 
