@@ -250,6 +250,11 @@ def main():
                          "kernel": {"megakernel": "k_trace", "wavefront": "k_wf_intersect + k_wf_shade", "pixel": "k_render_mega", "bvh": "k_trace (hierarchy walk)"}[args.mode], "flop_per_ray": flop_per_ray,
                          "note": "FP32 vector-ALU bound (HBM traffic and MFMA are not on this path); algorithmic flops = rays x (18 x spheres + 150)"},
         }
+        if args.mode == "bvh":
+            # the hierarchy walk skips most ray-sphere tests, so the brute-force flop count does not describe it
+            line["roofline"] = {"bound": "valu", "achieved": None, "peak": PEAK_FP32_VALU_TFLOPS, "unit": "TFLOP/s", "frac": None, "traffic": None,
+                                "kernel": "k_trace (hierarchy walk)",
+                                "note": "optional mode beyond the brute-force sweep: per-lane tree walk, latency-bound; compare ms_per_step with the megakernel's"}
         line.update(cpu_lines)
         checksum = int(img.to(torch.int64).sum().item()) if img is not None else None
         line["image_checksum"] = checksum
