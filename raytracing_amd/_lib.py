@@ -14,7 +14,7 @@ LAMBERTIAN, METAL, DIELECTRIC = 0, 1, 2
 # every symbol include/rt_amd.h declares
 EXPORTS = ["rt_device_count", "rt_create", "rt_destroy", "rt_last_error", "rt_upload_scene", "rt_set_camera",
            "rt_owned_rows", "rt_owned_pixels", "rt_render_device", "rt_render_stats", "rt_render_counters", "rt_render",
-           "rt_scene_grid", "rt_format_ppm", "rt_write_ppm", "rt_write_ppm_binary", "rt_encode_ppm_device", "rt_write_ppm_device", "rt_test_sphere_hit", "rt_test_scatter", "rt_test_get_ray",
+           "rt_scene_grid", "rt_build_hierarchy", "rt_format_ppm", "rt_write_ppm", "rt_write_ppm_binary", "rt_encode_ppm_device", "rt_write_ppm_device", "rt_test_sphere_hit", "rt_test_scatter", "rt_test_get_ray",
            "rt_test_philox"]
 
 
@@ -73,6 +73,7 @@ def load_library():
     L.rt_render_counters.argtypes = [vp, C.POINTER(Counters)]
     L.rt_render.argtypes = [vp, C.POINTER(Params), fp, ip, C.POINTER(C.c_uint64), C.POINTER(C.c_float)]
     L.rt_scene_grid.argtypes = [C.c_uint64, C.c_int, C.c_int, fp, C.c_int, C.POINTER(C.c_int)]
+    L.rt_build_hierarchy.argtypes = [C.c_int, fp, fp, fp, fp, fp, C.c_int, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32), C.POINTER(C.c_int32)]
     L.rt_format_ppm.argtypes = [ip, C.c_int, C.c_int, C.c_char_p, C.c_int64]
     L.rt_format_ppm.restype = C.c_int64
     L.rt_write_ppm.argtypes = [C.c_char_p, ip, C.c_int, C.c_int]
@@ -312,3 +313,22 @@ def write_ppm_binary(path, irgb):
     rc = load_library().rt_write_ppm_binary(os.fsencode(path), _ip(a.reshape(-1)), a.shape[1], a.shape[0])
     if rc != 0:
         raise RtError(rc, load_library().rt_last_error(None).decode())
+
+
+def build_hierarchy(table):
+    """rt_build_hierarchy on an (n, 9) scene table.  Returns (nodes[k, 8] float32 with the link in column 7's bits,
+    leaf_index, big, depth)."""
+    t = np.asarray(table, dtype=np.float64)
+    n = len(t)
+    cx, cy, cz, rad = _f32(t[:, 0]), _f32(t[:, 1]), _f32(t[:, 2]), _f32(t[:, 3])
+    nodes = np.zeros((2 * n + 2, 8), dtype=np.float32)
+    leaf = np.zeros(n + 1, dtype=np.uint32)
+    big = np.zeros(16, dtype=np.uint32)
+    counts = (C.c_int32 * 4)()
+    L = load_library()
+    u32 = C.POINTER(C.c_uint32)
+    rc = L.rt_build_hierarchy(n, _fp(cx), _fp(cy), _fp(cz), _fp(rad), _fp(nodes.reshape(-1)), len(nodes), leaf.ctypes.data_as(u32),
+                              big.ctypes.data_as(u32), counts)
+    if rc != 0:
+        raise RtError(rc, L.rt_last_error(None).decode())
+    return nodes[:counts[0]], leaf[:counts[1]], big[:counts[2]], counts[3]

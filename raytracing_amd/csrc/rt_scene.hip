@@ -1,5 +1,6 @@
 // Host-side scene generation (untimed setup): RandomScene() of main.cpp:41-83 generalised, with an explicit draw order.
 #include "rt_internal.hpp"
+#include "rt_bvh.hpp"
 
 extern "C" {
 
@@ -55,6 +56,21 @@ int rt_scene_grid(uint64_t seed, int half_extent, int max_small, float* table9, 
     put(-4.0f, 1.0f, 0.0f, 1.0f, RT_LAMBERTIAN, 0.4f, 0.2f, 0.1f, 0.0f);
     put(4.0f, 1.0f, 0.0f, 1.0f, RT_METAL, 0.7f, 0.6f, 0.5f, 0.0f);
     *n_out = n;
+    return RT_OK;
+}
+
+// The hierarchy RT_MODE_BVH walks, built on the host exactly as rt_upload_scene builds it, copied out for inspection.
+int rt_build_hierarchy(int n, const float* cx, const float* cy, const float* cz, const float* radius,
+                       float* nodes8, int node_cap, uint32_t* leaf_index, uint32_t* big, int32_t counts[4])
+{
+    if (n <= 0 || !cx || !cy || !cz || !radius || !nodes8 || !leaf_index || !big || !counts) return fail(nullptr, RT_ERR_INVALID, "rt_build_hierarchy: bad argument");
+    BvhHost tree;
+    if (!build_bvh(n, cx, cy, cz, radius, &tree)) return fail(nullptr, RT_ERR_TOO_LARGE, "rt_build_hierarchy: hierarchy deeper than %d levels", kBvhStack - 2);
+    if (tree.node_count() > node_cap) return fail(nullptr, RT_ERR_TOO_LARGE, "rt_build_hierarchy: %d nodes, capacity %d", tree.node_count(), node_cap);
+    memcpy(nodes8, tree.nodes.data(), tree.nodes.size() * sizeof(float4));
+    memcpy(leaf_index, tree.leaf_index.data(), tree.leaf_index.size() * sizeof(uint32_t));
+    if (!tree.big.empty()) memcpy(big, tree.big.data(), tree.big.size() * sizeof(uint32_t));
+    counts[0] = tree.node_count(); counts[1] = (int32_t)tree.leaf_index.size(); counts[2] = (int32_t)tree.big.size(); counts[3] = tree.depth;
     return RT_OK;
 }
 
