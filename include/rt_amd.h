@@ -139,7 +139,7 @@ int rt_render(rt_context *ctx, const rt_params *p, float *h_rgb_mean, int32_t *h
 int rt_scene_grid(uint64_t seed, int half_extent, int max_small, float *table9, int cap, int *n_out);
 
 /* The hierarchy of sphere-centre boxes that RT_MODE_BVH walks instead of the loop of hittablelist.cpp:21-29, as
- * rt_upload_scene builds it (host only, no GPU needed).  nodes8: node_cap rows of (cmin.xyz, rmax, cmax.xyz, link);
+ * rt_upload_scene builds it (host only, no GPU needed).  nodes8: node_cap rows of (cmin.xyz, rmax (rounded up by a margin), cmax.xyz, link);
  * link is an int32 stored in the float's bits: >= 0 inner node with children link and link + 1, < 0 leaf with
  * -(link + 1) = first * 8 + (count - 1) into leaf_index.  big: spheres every ray tests directly (at most 16).
  * leaf_index needs n entries, big 16.  counts = (nodes, leaf entries, big entries, depth). */

@@ -2,12 +2,12 @@
 // hittablelist.cpp:13-31: same closest hit, found without visiting every sphere).
 //
 // The hierarchy is built over the sphere CENTRES: every node stores the bounding box of the centres below it
-// and the largest |radius| below it.  The traversal inflates that box per ray (radius plus an allowance for the
+// and (a hair more than) the largest |radius| below it.  The traversal inflates that box per ray (radius plus an allowance for the
 // rounding of the reference's discriminant, which grows with the distance of the ray origin), so nothing about a
 // particular ray is baked in here.  Spheres that are large next to the rest (the r = 1000 ground of the final
 // scene) would blow every ancestor's box up; they are kept in a short list that every ray tests directly.
 //
-// Layout: node i = two float4, nodes[2i] = (cmin.xyz, rmax), nodes[2i+1] = (cmax.xyz, link as int bits).
+// Layout: node i = two float4, nodes[2i] = (cmin.xyz, rmax plus 1e-6 (|cmin| + |cmax|) for the slab test's rounding), nodes[2i+1] = (cmax.xyz, link as int bits).
 // link >= 0: inner node, children at link and link + 1.  link < 0: leaf, -(link + 1) = first * 8 + (count - 1),
 // sphere indices leaf_index[first .. first + count), ascending inside a leaf.
 #pragma once
@@ -21,7 +21,10 @@
 
 namespace rt {
 
-constexpr int kBvhLeafSize = 4;
+#ifndef RT_BVH_LEAF
+#define RT_BVH_LEAF 4
+#endif
+constexpr int kBvhLeafSize = RT_BVH_LEAF;     // at most 8 (the leaf code keeps count - 1 in three bits)
 constexpr int kBvhMaxBig = 16;
 constexpr int kBvhStack = 24;       // traversal stack entries per lane; the builder refuses deeper trees
 
@@ -70,7 +73,11 @@ struct Builder {
             build(link + 1, mid, hi, depth + 1);
         }
         float linkf; std::memcpy(&linkf, &link, sizeof linkf);
-        out->nodes[2 * (size_t)self] = make_float4(mn[0], mn[1], mn[2], rmax);
+        // the radius the traversal inflates the box by, with the box's share of the slab test's absolute margin
+        float margin = 0.0f;
+        for (int a = 0; a < 3; ++a) margin += std::fabs(mn[a]) + std::fabs(mx[a]);
+        const float rpad = std::nextafter(rmax + 1e-6f * margin, INFINITY);
+        out->nodes[2 * (size_t)self] = make_float4(mn[0], mn[1], mn[2], rpad);
         out->nodes[2 * (size_t)self + 1] = make_float4(mx[0], mx[1], mx[2], linkf);
     }
 };

@@ -482,7 +482,8 @@ __device__ __forceinline__ void closest_hit_few(const RayD& ray, float tmin, con
 //     sqrt(r^2 + 19 u |o - c|^2 + 6 u r^2) from the centre.  A node's centre box is therefore inflated by
 //     sqrt(rmax^2 + 24 u (D^2 + rmax^2)), D = distance from the ray origin to the farthest corner of the box
 //     (>= |o - c| for every sphere below);
-//   * the slab test's own rounding is covered by a further relative 1e-5 and an absolute 1e-6 (1 + |o| + |box|).
+//   * the slab test's own rounding is covered by a further relative 1e-5 and an absolute 1e-6 (1 + |o| + |box|),
+//     the box's part of which the builder adds to the radius stored in the node.
 // The closest hit over a set of spheres is the smallest accepted root, equal roots going to the lower index
 // (hittablelist.cpp:21-29 keeps the first of equal ones and visits in index order); spheres are met here in
 // tree order, so the tie is resolved explicitly.
@@ -505,7 +506,7 @@ __device__ __forceinline__ void bvh_test_sphere(const RayD& ray, float qa, float
 }
 
 // Conservative ray / inflated-centre-box test of one node (see above).  Returns the entry parameter in t_in.
-__device__ __forceinline__ bool bvh_enter(const RayD& ray, float ix, float iy, float iz, float omag, float t_low, float closest,
+__device__ __forceinline__ bool bvh_enter(const RayD& ray, float ix, float iy, float iz, float ray_margin, float t_low, float closest,
                                           const float4 A, const float4 B, float& t_in)
 {
     const float fx = fmaxf(fabsf(ray.o.x - A.x), fabsf(ray.o.x - B.x));
@@ -513,8 +514,9 @@ __device__ __forceinline__ bool bvh_enter(const RayD& ray, float ix, float iy, f
     const float fz = fmaxf(fabsf(ray.o.z - A.z), fabsf(ray.o.z - B.z));
     const float far2 = fmaf(fx, fx, fmaf(fy, fy, fz * fz));
     const float r2 = A.w * A.w;
-    float pad = sqrtf(fmaf(kBvhSlack, far2 + r2, r2));
-    pad = fmaf(pad, 1.00001f, 1e-6f * (1.0f + omag + fabsf(A.x) + fabsf(A.y) + fabsf(A.z) + fabsf(B.x) + fabsf(B.y) + fabsf(B.z)));
+    // A.w already carries the node's share of the absolute margin (1e-6 (|cmin| + |cmax|), added by the builder);
+    // the hardware square root (1 ulp) is inside the relative 1e-5
+    const float pad = fmaf(__builtin_amdgcn_sqrtf(fmaf(kBvhSlack, far2 + r2, r2)), 1.00001f, ray_margin);
     const float ax = (A.x - pad - ray.o.x) * ix, bx = (B.x + pad - ray.o.x) * ix;
     const float ay = (A.y - pad - ray.o.y) * iy, by = (B.y + pad - ray.o.y) * iy;
     const float az = (A.z - pad - ray.o.z) * iz, bz = (B.z + pad - ray.o.z) * iz;
@@ -533,7 +535,7 @@ __device__ __forceinline__ void closest_hit_bvh(const RayD& ray, float tmin, con
     const float qa = dot(ray.d, ray.d);
     for (int j = 0; j < bv.n_big; ++j) bvh_test_sphere<kLds>(ray, qa, tmin, bv, s_geom, (int)bv.big[j], closest, hit);
     const float ix = 1.0f / ray.d.x, iy = 1.0f / ray.d.y, iz = 1.0f / ray.d.z;
-    const float omag = fabsf(ray.o.x) + fabsf(ray.o.y) + fabsf(ray.o.z);
+    const float omag = 1e-6f * (1.0f + fabsf(ray.o.x) + fabsf(ray.o.y) + fabsf(ray.o.z));     // the ray's share of the absolute margin
     const float t_low = tmin < 0.0f ? -FLT_MAX : 0.0f;
     auto test_leaf = [&](int link) {
         const int code = -(link + 1), first = code >> 3, count = (code & 7) + 1;
