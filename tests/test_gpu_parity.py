@@ -497,3 +497,24 @@ def test_tile_work_order_is_invisible_and_follows_scene_camera_and_rows(rt, monk
     got = rt.render(rt.params(**kw_rows))[:3]
     ref = fresh(three, cam_b, kw_rows, env="image")
     assert got[0].shape == ref[0].shape and got[2] == ref[2] and mismatch(got[0], ref[0]) == 0
+
+
+@pytest.mark.parametrize("distance", [60.0, 400.0, 3000.0, 20000.0])
+def test_far_telephoto_camera_where_the_reference_discriminant_is_noisy(rt, distance):
+    """Seen from far away through a narrow lens, the reference's float discriminant b*b - a*c loses its digits:
+    it reports hits for lines that pass well outside a sphere.  Filters and hierarchy boxes carry an allowance for
+    exactly that; here the sphere field is looked at from up to 20 000 units, and the filtered megakernel, the
+    wavefront kernels and the hierarchy walk must still agree bit for bit with the literal per-sphere kernel."""
+    W, H, S = 64, 40, 4
+    rt.upload_scene(R.final_scene_table())
+    direction = np.array([13.0, 2.0, 3.0]) / np.linalg.norm([13.0, 2.0, 3.0])
+    look_from = direction * distance
+    vfov = float(np.degrees(2.0 * np.arctan(6.0 / distance)))         # the field of small spheres fills the frame
+    cam = R.Camera(look_from, (0.0, 0.0, 0.0), (0.0, 1.0, 0.0), vfov, np.float32(W) / np.float32(H), 0.0, distance)
+    rt.set_camera(cam)
+    lit = rt.render(rt.params(W, H, S, seed=77, mode=R.MODE_PIXEL))
+    assert np.isfinite(lit[0]).all()
+    for mode in (R.MODE_MEGAKERNEL, R.MODE_WAVEFRONT, R.MODE_BVH):
+        got = rt.render(rt.params(W, H, S, seed=77, mode=mode))
+        assert got[2] == lit[2], (distance, mode)
+        assert mismatch(got[0], lit[0]) == 0, (distance, mode, mismatch(got[0], lit[0]))
