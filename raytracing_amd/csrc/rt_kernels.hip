@@ -781,8 +781,9 @@ __global__ void __launch_bounds__(kTraceBlock) k_trace(const TraceArgs a)
         while (need != 0ull && !(exhausted && pool_next == pool_end)) {
             if (pool_next == pool_end) {
                 unsigned int g = 0;
-                // Chunks shrink towards the end of the work (down to a floor that keeps the hand-out cheap next to the sweep) so that the waves run out of items
-                // at nearly the same time: with full-size chunks to the last, a wave can start a whole chunk
+                // Chunks shrink towards the end of the work (down to a floor that keeps the hand-out cheap next to
+                // the sweep) so that the waves run out of items at nearly the same time: with full-size chunks to the
+                // last, a wave can start a whole chunk
                 // (some twenty trips) just before the counter runs dry while its neighbours go idle.  What is left
                 // is estimated from this wave's previous reservation and one chunk per resident wave since.
                 uint32_t take = (uint32_t)a.chunk_items;
