@@ -2,12 +2,13 @@
 // hittablelist.cpp:13-31: same closest hit, found without visiting every sphere).
 //
 // The hierarchy is built over the sphere CENTRES: every node stores the bounding box of the centres below it
-// and (a hair more than) the largest |radius| below it.  The traversal inflates that box per ray (radius plus an allowance for the
-// rounding of the reference's discriminant, which grows with the distance of the ray origin), so nothing about a
-// particular ray is baked in here.  Spheres that are large next to the rest (the r = 1000 ground of the final
+// and (a hair more than) the largest |radius| below it.  The traversal inflates that box per ray (radius plus an
+// allowance for the rounding of the reference's discriminant, which grows with the distance of the ray origin), so
+// nothing about a particular ray is baked in here.  Spheres that are large next to the rest (the r = 1000 ground of the final
 // scene) would blow every ancestor's box up; they are kept in a short list that every ray tests directly.
 //
-// Layout: node i = two float4, nodes[2i] = (cmin.xyz, rmax plus 1e-6 (|cmin| + |cmax|) for the slab test's rounding), nodes[2i+1] = (cmax.xyz, link as int bits).
+// Layout: node i = two float4, nodes[2i] = (cmin.xyz, rmax plus 1e-6 (|cmin| + |cmax|) for the slab test's rounding),
+// nodes[2i+1] = (cmax.xyz, link as int bits).
 // link >= 0: inner node, children at link and link + 1.  link < 0: leaf, -(link + 1) = first * 8 + (count - 1),
 // sphere indices leaf_index[first .. first + count), ascending inside a leaf.
 #pragma once

@@ -1,4 +1,5 @@
-// Host mirror of the reference's Ray (ray.h:6-21, ray.cpp): origin plus un-normalised direction.
+// A ray as the reference's host code knows it (ray.h:6-21): two public Vec3 members under the reference's
+// names, origin and an un-normalised direction, plus the three accessors its callers use.
 #pragma once
 #include "vec3.h"
 
@@ -7,9 +8,16 @@ public:
     Vec3 m_oOrigin;
     Vec3 m_oDirection;
 
-    Ray() {}
-    Ray(const Vec3& a, const Vec3& b) : m_oOrigin(a), m_oDirection(b) {}
+    Ray() = default;
+    Ray(const Vec3& origin, const Vec3& direction) : m_oOrigin(origin), m_oDirection(direction) {}
+
     Vec3 Origin() const { return m_oOrigin; }
     Vec3 Direction() const { return m_oDirection; }
-    Vec3 PointAtParamenter(float t) const { return m_oOrigin + t * m_oDirection; }   // spelling as in the reference
+
+    // origin + t * direction; the name is spelled as the reference spells it, callers depend on it
+    Vec3 PointAtParamenter(float t) const
+    {
+        const Vec3 along = t * m_oDirection;
+        return m_oOrigin + along;
+    }
 };
