@@ -353,6 +353,18 @@ def test_error_behaviour(rt):
     fresh.close()
     with pytest.raises(R.RtError):
         R.Renderer(99)
+    # the entry points added around the render call report misuse the same way
+    fresh = R.Renderer(0)
+    with pytest.raises(R.RtError) as e:
+        fresh.counters()                                          # nothing rendered yet
+    assert e.value.code == -4
+    with pytest.raises(R.RtError):
+        fresh.encode_ppm_device(0, 8, 8)                          # null image
+    fresh.upload_scene(R.three_sphere_table())
+    fresh.set_camera(R.three_camera(8, 8))
+    with pytest.raises(R.RtError):
+        fresh.render(fresh.params(8, 8, 1, mode=7))               # unknown kernel organisation
+    fresh.close()
 
 
 def test_ppm_text_encoded_on_the_gpu_equals_the_host_formatter(rt, tmp_path):
