@@ -426,6 +426,13 @@ __device__ __forceinline__ void closest_hit(const RayD& ray, float tmin, const S
 #ifndef RT_FEW_PATHS
 #define RT_FEW_PATHS 8
 #endif
+// depth of the deepest path a wave holds at which it is raised to issue priority 1, 2, 3 (4/8/16, 2/4/8, 12/20/32 and
+// 16/24/36 measure within the run-to-run spread of this choice, tools/ab_prio.sh)
+#ifndef RT_PRIO_1
+#define RT_PRIO_1 8
+#define RT_PRIO_2 16
+#define RT_PRIO_3 32
+#endif
 constexpr int kFewPaths = RT_FEW_PATHS;     // 2, 4 and 8 measure alike on the 1200x800 final scene at 10 spp, 16 and 24 are 4-6 % slower (tools/ab_few.sh)
 template <bool kLds>
 __device__ __forceinline__ void closest_hit_few(const RayD& ray, float tmin, const SweepScene& sw, const float4* s_geom,
@@ -850,7 +857,7 @@ __global__ void __launch_bounds__(kTraceBlock) k_trace(const TraceArgs a)
         // hold a deep path are therefore given issue priority over their neighbours (same total work, the long
         // chains just finish sooner).
         {
-            const int deepest = __any(active && depth >= 32) ? 3 : __any(active && depth >= 16) ? 2 : __any(active && depth >= 8) ? 1 : 0;
+            const int deepest = __any(active && depth >= RT_PRIO_3) ? 3 : __any(active && depth >= RT_PRIO_2) ? 2 : __any(active && depth >= RT_PRIO_1) ? 1 : 0;
             if (deepest == 3) __builtin_amdgcn_s_setprio(3);
             else if (deepest == 2) __builtin_amdgcn_s_setprio(2);
             else if (deepest == 1) __builtin_amdgcn_s_setprio(1);
