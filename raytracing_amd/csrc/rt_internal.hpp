@@ -24,6 +24,7 @@ struct rt_context {
     bool plane_filter = true;
     bool records_in_lds = false;      // measurement variant, RT_AMD_RECORDS=lds
     float* d_samples = nullptr; size_t samples_bytes = 0;      // sample buffer of the persistent megakernel
+    uint64_t sample_buffer_cap = 16ull << 30;                  // largest sample buffer per batch (bytes)
     float* d_accum = nullptr; size_t accum_bytes = 0;          // running per-pixel sums across sample batches
     unsigned int* d_work = nullptr;
     uint16_t* d_stacks = nullptr; size_t stacks_lanes = 0;

@@ -1112,6 +1112,8 @@ int rt_create(int device_ordinal, rt_context** out)
     { const char* f = getenv("RT_AMD_FILTER"); ctx->plane_filter = !(f && strcmp(f, "disc") == 0); }
     { const char* f = getenv("RT_AMD_RECORDS"); ctx->records_in_lds = (f && strcmp(f, "lds") == 0); }
     // RT_AMD_TILE_ORDER=image works through the tiles in image order instead of longest-paths-first (A/B runs).
+    // RT_AMD_SAMPLE_BUFFER_KB caps the sample buffer (tests use it to run the multi-batch path on small images).
+    { const char* f = getenv("RT_AMD_SAMPLE_BUFFER_KB"); const long long kb = f ? atoll(f) : 0; if (kb > 0) ctx->sample_buffer_cap = (uint64_t)kb << 10; }
     { const char* f = getenv("RT_AMD_TILE_ORDER"); ctx->tile_ordering = !(f && strcmp(f, "image") == 0); }
     hipError_t e = hipSetDevice(device_ordinal);
     if (e == hipSuccess) e = hipMalloc(&ctx->d_rays, 2 * sizeof(unsigned long long));
@@ -1271,7 +1273,7 @@ int rt_render_device(rt_context* ctx, const rt_params* p, float* d_rgb_mean, int
         const uint64_t Q = (uint64_t)tiles_x * tiles_y * 64;
         // sample batches: the per-batch sample buffer stays below 16 GiB (of 288 GB of HBM) and item ids below 2^31;
         // every batch ends with the drain of its longest paths, so fewer, larger batches are better
-        uint64_t per_batch = (16ull << 30) / (Q * 12);
+        uint64_t per_batch = ctx->sample_buffer_cap / (Q * 12);
         if (per_batch > (1ull << 31) / Q) per_batch = (1ull << 31) / Q;
         if (per_batch == 0) return fail(ctx, RT_ERR_TOO_LARGE, "rt_render_device: %llu pixels in one call exceed the sample-buffer limit; split the image into bands", (unsigned long long)Q);
         const int batches = (int)((p->spp + per_batch - 1) / per_batch);

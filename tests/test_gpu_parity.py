@@ -530,3 +530,27 @@ def test_far_telephoto_camera_where_the_reference_discriminant_is_noisy(rt, dist
         got = rt.render(rt.params(W, H, S, seed=77, mode=mode))
         assert got[2] == lit[2], (distance, mode)
         assert mismatch(got[0], lit[0]) == 0, (distance, mode, mismatch(got[0], lit[0]))
+
+
+@pytest.mark.parametrize("mode", [R.MODE_MEGAKERNEL, R.MODE_WAVEFRONT, R.MODE_BVH])
+def test_sample_batches_accumulate_in_sample_order(monkeypatch, mode):
+    """Large jobs render their samples in batches with a running per-pixel sum; the sum must still run over the
+    samples in ascending order (main.cpp:124-134).  A small cap on the sample buffer forces many batches here."""
+    m = _meta()["philox_final_40x30x16_ap0"]
+    want = np.load(os.path.join(G, "img_philox_final_40x30x16_ap0.npy"))
+    monkeypatch.setenv("RT_AMD_SAMPLE_BUFFER_KB", "64")          # 40x32 padded pixels x 12 B = 15 KB per sample: 4 samples per batch
+    r = R.Renderer(0)
+    monkeypatch.delenv("RT_AMD_SAMPLE_BUFFER_KB")
+    _setup(r, m)
+    rgb, irgb, rays, _ = r.render(r.params(m["nx"], m["ny"], m["ns"], seed=m["seed"], mode=mode))
+    assert rays == m["rays"] and r.counters() == (m["rays"], m["hits"], m["scatters"])
+    assert mismatch(rgb, want) == 0
+    # a cap below one sample of the image is an error, not a crash
+    monkeypatch.setenv("RT_AMD_SAMPLE_BUFFER_KB", "8")
+    tiny = R.Renderer(0)
+    monkeypatch.delenv("RT_AMD_SAMPLE_BUFFER_KB")
+    _setup(tiny, m)
+    with pytest.raises(R.RtError) as e:
+        tiny.render(tiny.params(m["nx"], m["ny"], m["ns"], seed=m["seed"], mode=mode))
+    assert e.value.code == -5
+    r.close(); tiny.close()
