@@ -46,6 +46,27 @@ class Counters(C.Structure):
 _lib = None
 
 
+def _share_hip_runtime_with_torch():
+    """PyTorch wheels carry their own copy of the HIP runtime (torch/lib/libamdhip64.so, soname libamdhip64.so.7, which
+    torch's libraries ask for by file name).  If librt_amd.so is loaded first it brings in the system copy under the
+    same soname, torch then loads its own copy as well, and the second runtime to start finds no GPU.  Loading torch's
+    copy first, when torch is installed and not yet imported, makes both sides use one runtime whatever the import
+    order.  Nothing here imports torch."""
+    import importlib.util
+    import sys
+    if "torch" in sys.modules:
+        return
+    try:
+        spec = importlib.util.find_spec("torch")
+        for base in (spec.submodule_search_locations or []) if spec else []:
+            path = os.path.join(base, "lib", "libamdhip64.so")
+            if os.path.exists(path):
+                C.CDLL(path, mode=C.RTLD_GLOBAL)
+                return
+    except Exception:
+        pass            # no torch, or an unusual installation: the system runtime is used
+
+
 def load_library():
     """Load librt_amd.so; raises if it has not been built (there is no fallback path)."""
     global _lib
@@ -54,6 +75,7 @@ def load_library():
     if not os.path.exists(LIB_PATH):
         raise RtError(-2, f"{LIB_PATH} is missing: build it with `make -C raytracing_amd/csrc` "
                           "(or __graft_entry__.build())")
+    _share_hip_runtime_with_torch()
     L = C.CDLL(LIB_PATH)
     fp, ip, vp = C.POINTER(C.c_float), C.POINTER(C.c_int32), C.c_void_p
     L.rt_device_count.argtypes = [C.POINTER(C.c_int)]

@@ -554,3 +554,31 @@ def test_sample_batches_accumulate_in_sample_order(monkeypatch, mode):
         tiny.render(tiny.params(m["nx"], m["ny"], m["ns"], seed=m["seed"], mode=mode))
     assert e.value.code == -5
     r.close(); tiny.close()
+
+
+def test_device_pointer_form_on_a_side_stream(rt):
+    """rt_render_device enqueues on the caller's stream and returns; outputs land in caller-owned device memory."""
+    import torch
+    rt.upload_scene(R.final_scene_table())
+    rt.set_camera(R.final_camera(96, 64))
+    p = rt.params(96, 64, 3, seed=31)
+    want_rgb, want_i, want_rays, _ = rt.render(p)
+    d_rgb = torch.zeros((64, 96, 3), dtype=torch.float32, device="cuda")      # (first: torch initialises its GPU state lazily)
+    d_i = torch.zeros((64, 96, 3), dtype=torch.int32, device="cuda")
+    side = torch.cuda.Stream()
+    for mode in (R.MODE_MEGAKERNEL, R.MODE_WAVEFRONT, R.MODE_PIXEL, R.MODE_BVH):
+        d_rgb.zero_(); d_i.zero_()
+        torch.cuda.synchronize()
+        rt.render_device(rt.params(96, 64, 3, seed=31, mode=mode), d_rgb.data_ptr(), d_i.data_ptr(), side.cuda_stream)
+        rays, ms = rt.stats()                                     # waits for the work on the side stream
+        assert rays == want_rays and ms > 0.0
+        assert mismatch(d_rgb.cpu().numpy(), want_rgb) == 0 and np.array_equal(d_i.cpu().numpy(), want_i)
+    # only one of the two outputs requested
+    d_i.zero_(); torch.cuda.synchronize()
+    rt.render_device(p, 0, d_i.data_ptr(), side.cuda_stream)
+    rt.stats()
+    assert np.array_equal(d_i.cpu().numpy(), want_i)
+    d_rgb.zero_(); torch.cuda.synchronize()
+    rt.render_device(p, d_rgb.data_ptr(), 0, side.cuda_stream)
+    rt.stats()
+    assert mismatch(d_rgb.cpu().numpy(), want_rgb) == 0
