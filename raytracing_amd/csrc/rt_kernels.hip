@@ -216,7 +216,7 @@ struct TraceArgs {
 #ifdef RT_WAVE_TIMELINE
 // Diagnostic build (-DRT_WAVE_TIMELINE), per wave of the last k_trace launch: s_memrealtime (100 MHz, common to all XCDs) at entry, when the wave first found the work counter dry, at exit;
 // and how many trips of the main loop it made after that point
-__device__ unsigned long long g_wave_times[6][8192];      // rows 4, 5: trips made with the sparse sweep, ticks spent in those trips (whole trip)
+__device__ unsigned long long g_wave_times[8][8192];      // rows 4, 5: trips made with the sparse sweep, ticks spent in those trips (whole trip); 6: first sweep starts; 7: first trip ends
 #endif
 #ifdef RT_SECTION_TIMERS
 __device__ unsigned long long g_section_ticks[8];
@@ -769,6 +769,7 @@ __global__ void __launch_bounds__(kTraceBlock) k_trace(const TraceArgs a)
     uint32_t pool_next = 0, pool_end = 0, pool_base = 0;      // wave-uniform
     float* staged = a.staging + ((size_t)blockIdx.x * (kTraceBlock / 64) + wave) * (kStagingRows * kChunkItems);
     bool exhausted = false;                    // wave-uniform
+    bool first_chunk = true;                   // wave-uniform
     const float fnx = (float)a.width, fny = (float)a.height;
     SecTimer T; T.start();
     ItemGeometry ig; ig.width = a.width; ig.height = a.height; ig.band_rows = a.band_rows; ig.band_first = a.band_first; ig.band_step = a.band_step;
@@ -776,7 +777,7 @@ __global__ void __launch_bounds__(kTraceBlock) k_trace(const TraceArgs a)
     SweepScene sw; sw.frec = a.frec; sw.prec = a.prec; sw.plane_s0 = a.plane_s0; sw.plane_rmin = a.plane_rmin; sw.geom = a.geom; sw.n = a.n; sw.n_pad = a.n_pad;
 
 #ifdef RT_WAVE_TIMELINE
-    const unsigned long long t_enter = __builtin_amdgcn_s_memrealtime(); unsigned long long t_dry = 0, trips_dry = 0, sparse_trips = 0, sparse_ticks = 0, t_trip = 0; bool was_sparse = false;
+    const unsigned long long t_enter = __builtin_amdgcn_s_memrealtime(); unsigned long long t_dry = 0, trips_dry = 0, sparse_trips = 0, sparse_ticks = 0, t_trip = 0, t_first_sweep = 0, t_first_done = 0; bool was_sparse = false;
 #endif
     for (;;) {
 #ifdef RT_WAVE_TIMELINE
@@ -800,8 +801,17 @@ __global__ void __launch_bounds__(kTraceBlock) k_trace(const TraceArgs a)
                     const uint32_t fair = (left / (a.resident_waves * 2u)) & ~63u;
                     if (fair < take) take = fair < a.min_chunk_items ? a.min_chunk_items : fair;
                 }
-                if (lane == 0) g = atomicAdd(a.work_counter, take);
-                g = __builtin_amdgcn_readfirstlane(g);
+                if (first_chunk) {
+                    // every wave's first chunk is fixed by its position in the grid (the host starts the counter
+                    // behind them): thousands of waves asking one counter word at the same instant would queue
+                    // for some 70 us at the start of every launch
+                    first_chunk = false;
+                    take = (uint32_t)a.chunk_items;
+                    g = (blockIdx.x * (uint32_t)(kTraceBlock / 64) + (uint32_t)wave) * take;
+                } else {
+                    if (lane == 0) g = atomicAdd(a.work_counter, take);
+                    g = __builtin_amdgcn_readfirstlane(g);
+                }
                 if (g >= a.total_items) { exhausted = true; break; }
                 pool_next = g; pool_base = g;
                 pool_end = (a.total_items - g < take) ? a.total_items : g + take;
@@ -867,6 +877,8 @@ __global__ void __launch_bounds__(kTraceBlock) k_trace(const TraceArgs a)
         const unsigned long long live = __ballot(active);
 #ifdef RT_WAVE_TIMELINE
         was_sparse = __popcll(live) <= kFewPaths && live != 0ull;
+        if (t_first_sweep == 0) t_first_sweep = __builtin_amdgcn_s_memrealtime();
+        else if (t_first_done == 0) t_first_done = __builtin_amdgcn_s_memrealtime();
 #endif
         if (kBvh) { if (active) closest_hit_bvh<kLds>(ray, a.tmin, a.bvh, s_geom, mask_words, closest, hit); }
         else if (__popcll(live) <= kFewPaths) closest_hit_few<kLds>(ray, a.tmin, sw, s_geom, live, lane, closest, hit);
@@ -889,7 +901,7 @@ __global__ void __launch_bounds__(kTraceBlock) k_trace(const TraceArgs a)
 #ifdef RT_WAVE_TIMELINE
     {
         const uint32_t w = blockIdx.x * (kTraceBlock / 64) + wave;
-        if (lane == 0 && w < 8192u) { g_wave_times[0][w] = t_enter; const unsigned long long t_exit = __builtin_amdgcn_s_memrealtime(); g_wave_times[1][w] = t_dry ? t_dry : t_exit; g_wave_times[2][w] = t_exit; g_wave_times[3][w] = trips_dry; g_wave_times[4][w] = sparse_trips; g_wave_times[5][w] = sparse_ticks; }
+        if (lane == 0 && w < 8192u) { g_wave_times[0][w] = t_enter; const unsigned long long t_exit = __builtin_amdgcn_s_memrealtime(); g_wave_times[1][w] = t_dry ? t_dry : t_exit; g_wave_times[2][w] = t_exit; g_wave_times[3][w] = trips_dry; g_wave_times[4][w] = sparse_trips; g_wave_times[5][w] = sparse_ticks; g_wave_times[6][w] = t_first_sweep; g_wave_times[7][w] = t_first_done; }
     }
 #endif
     // one atomic per wave
@@ -1080,9 +1092,9 @@ extern "C" int rt_debug_section_ticks(unsigned long long* out8, int reset)
 }
 #endif
 #ifdef RT_WAVE_TIMELINE
-extern "C" int rt_debug_wave_times(unsigned long long* out_6x8192)
+extern "C" int rt_debug_wave_times(unsigned long long* out_6x8192)   /* 8 rows of 8192 */
 {
-    return hipMemcpyFromSymbol(out_6x8192, HIP_SYMBOL(g_wave_times), 6 * 8192 * sizeof(unsigned long long)) == hipSuccess ? 0 : -3;
+    return hipMemcpyFromSymbol(out_6x8192, HIP_SYMBOL(g_wave_times), 8 * 8192 * sizeof(unsigned long long)) == hipSuccess ? 0 : -3;
 }
 #endif
 
@@ -1414,7 +1426,6 @@ int rt_render_device(rt_context* ctx, const rt_params* p, float* d_rgb_mean, int
             a.stacks = ctx->d_stacks; a.stack_stride = (uint32_t)ctx->stacks_lanes; a.staging = ctx->d_staging;
             a.tile_order = ordered ? ctx->d_tile_order : nullptr;
             a.bvh.nodes = ctx->d_bvh_nodes; a.bvh.leaf_index = ctx->d_bvh_leaf; a.bvh.big = ctx->d_bvh_big; a.bvh.n_big = ctx->bvh_n_big; a.bvh.geom = ctx->d_geom;
-            HIP_TRY(ctx, hipMemsetAsync(ctx->d_work, 0, sizeof(unsigned int), st));
             // small jobs take smaller chunks so that every resident wave gets several (tail balance)
             const uint64_t resident_waves = (uint64_t)ctx->num_cu * bpc * (kTraceBlock / 64);
             uint64_t chunk = (uint64_t)a.total_items / (resident_waves * 16) / 64 * 64;
@@ -1426,6 +1437,8 @@ int rt_render_device(rt_context* ctx, const rt_params* p, float* d_rgb_mean, int
             uint64_t want_blocks = ((uint64_t)a.total_items + (uint64_t)a.chunk_items * (kTraceBlock / 64) - 1) / ((uint64_t)a.chunk_items * (kTraceBlock / 64));
             const uint64_t cap_blocks = (uint64_t)ctx->num_cu * bpc;
             const dim3 grid((unsigned)(want_blocks < cap_blocks ? want_blocks : cap_blocks)), block(kTraceBlock);
+            // the first chunk of every launched wave is implied by its index; the counter hands out what follows
+            HIP_TRY(ctx, hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(ctx->d_work), (int)(grid.x * (unsigned)(kTraceBlock / 64) * (unsigned)a.chunk_items), 1, st));
             if (bvh && lds) hipLaunchKernelGGL((k_trace<true, true, false, true>), grid, block, shmem, st, a);
             else if (bvh) hipLaunchKernelGGL((k_trace<false, true, false, true>), grid, block, shmem, st, a);
             else if (reclds) hipLaunchKernelGGL((k_trace<true, true, true>), grid, block, shmem, st, a);

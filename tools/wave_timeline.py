@@ -19,7 +19,7 @@ rt = R.Renderer(0)
 rt.upload_scene(R.final_scene_table())
 rt.set_camera(R.final_camera(1200, 800))
 L = R.load_library()
-buf = np.zeros((6, 8192), dtype=np.uint64)
+buf = np.zeros((8, 8192), dtype=np.uint64)
 for rep in range(2):
     band = next(b for b in (8, 4, 2, 1) if (800 // b) % ranks == 0)
     rgb, irgb, rays, ms = rt.render(rt.params(1200, 800, spp, seed=0, max_depth=depth, band_rows=band, band_first=0, band_step=ranks))
@@ -40,3 +40,6 @@ print("waves still running at t (us):", ", ".join(f"{e:.0f}:{a}" for e, a in zip
 st, sk = buf[4][live].astype(np.float64), buf[5][live].astype(np.float64) / 100.0
 print("sparse trips: total %d, mean %.2f us per trip; waves with > 20 sparse trips: %d, their mean trip %.2f us" %
       (st.sum(), sk.sum() / max(st.sum(), 1), (st > 20).sum(), sk[st > 20].sum() / max(st[st > 20].sum(), 1)))
+fs = (buf[6][live].astype(np.int64) - int(t0)) / 100.0
+fd = (buf[7][live].astype(np.int64) - int(t0)) / 100.0
+print("first sweep starts us: min %.0f median %.0f max %.0f;  second trip's sweep starts us: median %.0f max %.0f" % (fs.min(), np.median(fs), fs.max(), np.median(fd), fd.max()))
