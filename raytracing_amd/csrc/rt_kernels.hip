@@ -1000,11 +1000,33 @@ __global__ void __launch_bounds__(kTraceBlock) k_wf_intersect(const WfArgs a)
     }
 }
 
-__global__ void __launch_bounds__(256) k_wf_shade(const WfArgs a)
+// One reservation on a global counter for a whole block: every wave contributes `mine` (wave-uniform), thread 0 adds
+// the block's total with a single atomic, and each wave gets the start of its share.  Returns the block's total.
+// A single counter word takes about 88 atomics per microsecond on this chip; one per wave, with 131 072 waves per
+// pass, made the counters the bottleneck of the shade pass.
+constexpr int kWfShadeBlock = 1024;
+__device__ __forceinline__ uint32_t block_reserve(uint32_t* counter, uint32_t mine, int wave, int lane, uint32_t* s_counts, uint32_t* s_base, uint32_t& my_base)
 {
-    const int lane = threadIdx.x & 63;
+    if (lane == 0) s_counts[wave] = mine;
+    __syncthreads();
+    uint32_t before = 0, total = 0;
+    for (int w = 0; w < kWfShadeBlock / 64; ++w) { const uint32_t c = s_counts[w]; before += w < wave ? c : 0u; total += c; }
+    if (threadIdx.x == 0 && total != 0u) *s_base = atomicAdd(counter, total);
+    __syncthreads();
+    my_base = *s_base + before;
+    __syncthreads();            // s_counts and s_base are reused by the next reservation
+    return total;
+}
+
+__global__ void __launch_bounds__(kWfShadeBlock) k_wf_shade(const WfArgs a)
+{
+    __shared__ uint32_t s_counts[kWfShadeBlock / 64];
+    __shared__ uint32_t s_base;
+    __shared__ unsigned long long s_rays[2];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    if (threadIdx.x < 2) s_rays[threadIdx.x] = 0ull;
     const uint32_t n_in = *a.n_in;
-    const uint32_t e = blockIdx.x * 256u + threadIdx.x;
+    const uint32_t e = blockIdx.x * (uint32_t)kWfShadeBlock + threadIdx.x;
     bool live = e < n_in;
     bool traced = false;          // this lane's ray went through a closest-hit query
     bool missed = false;          // ... and hit nothing
@@ -1032,17 +1054,14 @@ __global__ void __launch_bounds__(256) k_wf_shade(const WfArgs a)
         if (done) live = false;
         ray_o = ray.o; ray_d = ray.d; depth_out = depth; pix_out = pix; smp_out = smp;
     }
-    // A finished slot takes the next (pixel, sample) item.  Items are reserved per wave: ballot of the lanes
-    // that need one, one atomic for the whole wave, prefix rank per lane.  (One atomic per lane on the single
-    // counter word costs about a millisecond per pass at 8 M rays.)  Padding pixels of edge tiles are skipped
-    // by asking again.
+    // A finished slot takes the next (pixel, sample) item.  Items are reserved per block: ballot of the lanes
+    // that need one, the waves' counts summed in LDS, one atomic for the block, prefix rank per lane.  Padding
+    // pixels of edge tiles are skipped by asking again (the loop count is the same for all threads of the block).
     uint32_t item_out = 0;
     for (;;) {
         const unsigned long long want = __ballot(need);
-        if (want == 0ull) break;
         uint32_t base = 0;
-        if (lane == 0) base = atomicAdd(a.work_counter, (uint32_t)__popcll(want));
-        base = __builtin_amdgcn_readfirstlane(base);
+        if (block_reserve(a.work_counter, (uint32_t)__popcll(want), wave, lane, s_counts, &s_base, base) == 0u) break;
         if (need) {
             const uint32_t it = base + __builtin_amdgcn_mbcnt_hi((uint32_t)(want >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)want, 0u));
             int i = 0, j = 0; uint32_t store_unused = 0;
@@ -1060,16 +1079,14 @@ __global__ void __launch_bounds__(256) k_wf_shade(const WfArgs a)
         if (fresh) { a.pixsmp[0 * (size_t)a.P + s] = pix_out; a.pixsmp[1 * (size_t)a.P + s] = smp_out; a.pixsmp[2 * (size_t)a.P + s] = item_out; }
     }
     const unsigned long long did = __ballot(traced), sky_end = __ballot(missed);
-    if (lane == 0 && did != 0ull) { atomicAdd(a.ray_counter, (unsigned long long)__popcll(did)); atomicAdd(a.ray_counter + 1, (unsigned long long)__popcll(sky_end)); }
-    // compaction: ballot of surviving lanes, prefix rank within the wave, one atomic per wave
+    if (lane == 0 && did != 0ull) { atomicAdd(&s_rays[0], (unsigned long long)__popcll(did)); atomicAdd(&s_rays[1], (unsigned long long)__popcll(sky_end)); }
+    // compaction: ballot of surviving lanes, prefix rank within the wave, the waves' counts summed in LDS, one atomic per block
     const unsigned long long alive = __ballot(live);
-    if (alive != 0ull) {
-        uint32_t base = 0;
-        if (lane == 0) base = atomicAdd(a.n_out, (uint32_t)__popcll(alive));
-        base = __builtin_amdgcn_readfirstlane(base);
-        const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(alive >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)alive, 0u));
-        if (live) a.q_out[base + rank] = s;
-    }
+    uint32_t base = 0;
+    (void)block_reserve(a.n_out, (uint32_t)__popcll(alive), wave, lane, s_counts, &s_base, base);      // its barriers also publish s_rays
+    const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(alive >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)alive, 0u));
+    if (live) a.q_out[base + rank] = s;
+    if (threadIdx.x == 0 && s_rays[0] != 0ull) { atomicAdd(a.ray_counter, s_rays[0]); atomicAdd(a.ray_counter + 1, s_rays[1]); }
 }
 
 // ============================================================================ host side
@@ -1397,7 +1414,7 @@ int rt_render_device(rt_context* ctx, const rt_params* p, float* d_rgb_mean, int
                     HIP_TRY(ctx, hipMemsetAsync(ctx->wf_n + (cur ^ 1), 0, sizeof(uint32_t), st));
                     unsigned ib = (live_upper + kTraceBlock - 1) / kTraceBlock; if (ib > igrid_cap) ib = igrid_cap; if (ib == 0) ib = 1;
                     hipLaunchKernelGGL(ikern, dim3(ib), dim3(kTraceBlock), wshmem, st, w);
-                    hipLaunchKernelGGL(k_wf_shade, dim3((live_upper + 255) / 256), dim3(256), 0, st, w);
+                    hipLaunchKernelGGL(k_wf_shade, dim3((live_upper + kWfShadeBlock - 1) / kWfShadeBlock), dim3(kWfShadeBlock), 0, st, w);
                     HIP_TRY(ctx, hipGetLastError());
                     cur ^= 1;
                     if ((iter & 7) == 7) {              // the host steers the loop: read the live count every 8 bounces
