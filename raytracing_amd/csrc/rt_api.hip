@@ -1,0 +1,303 @@
+// The extern "C" layer of librt_amd.so for contexts, scenes, cameras and renders (include/rt_amd.h).  The kernels and
+// their launchers are in rt_pixel.hip, rt_trace.hip and rt_wavefront.hip.
+#include <hip/hip_runtime.h>
+#include <cfloat>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <new>
+#include <string>
+#include <type_traits>
+#include <vector>
+#include "rt_internal.hpp"
+#include "rt_bvh.hpp"
+
+static thread_local std::string g_error;
+
+int fail(rt_context* ctx, int code, const char* fmt, ...)
+{
+    char buf[512];
+    va_list ap; va_start(ap, fmt); vsnprintf(buf, sizeof buf, fmt, ap); va_end(ap);
+    if (ctx) ctx->error = buf; else g_error = buf;
+    return code;
+}
+
+extern "C" {
+
+int rt_device_count(int* count)
+{
+    if (!count) return fail(nullptr, RT_ERR_INVALID, "rt_device_count: null output");
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess) { *count = 0; return fail(nullptr, RT_ERR_NO_DEVICE, "hipGetDeviceCount: %s", hipGetErrorString(e)); }
+    *count = n;
+    return RT_OK;
+}
+
+int rt_create(int device_ordinal, rt_context** out)
+{
+    if (!out) return fail(nullptr, RT_ERR_INVALID, "rt_create: null output");
+    *out = nullptr;
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess || n <= 0) return fail(nullptr, RT_ERR_NO_DEVICE, "rt_create: no HIP device visible");
+    if (device_ordinal < 0 || device_ordinal >= n) return fail(nullptr, RT_ERR_NO_DEVICE, "rt_create: device %d out of range [0,%d)", device_ordinal, n);
+    rt_context* ctx = new (std::nothrow) rt_context;
+    if (!ctx) return fail(nullptr, RT_ERR_HIP, "rt_create: out of host memory");
+    ctx->device = device_ordinal;
+    // RT_AMD_FILTER=disc selects the full-discriminant filter instead of the plane filter (A/B runs).
+    { const char* f = getenv("RT_AMD_FILTER"); ctx->plane_filter = !(f && strcmp(f, "disc") == 0); }
+    { const char* f = getenv("RT_AMD_RECORDS"); ctx->records_in_lds = (f && strcmp(f, "lds") == 0); }
+    // RT_AMD_TILE_ORDER=image works through the tiles in image order instead of longest-paths-first (A/B runs).
+    // RT_AMD_SAMPLE_BUFFER_KB caps the sample buffer (tests use it to run the multi-batch path on small images).
+    { const char* f = getenv("RT_AMD_SAMPLE_BUFFER_KB"); const long long kb = f ? atoll(f) : 0; if (kb > 0) ctx->sample_buffer_cap = (uint64_t)kb << 10; }
+    { const char* f = getenv("RT_AMD_TILE_ORDER"); ctx->tile_ordering = !(f && strcmp(f, "image") == 0); }
+    hipError_t e = hipSetDevice(device_ordinal);
+    if (e == hipSuccess) e = hipMalloc(&ctx->d_rays, 2 * sizeof(unsigned long long));
+    if (e == hipSuccess) e = hipMalloc(&ctx->d_work, sizeof(unsigned int));
+    if (e == hipSuccess) { hipDeviceProp_t prop; e = hipGetDeviceProperties(&prop, device_ordinal); if (e == hipSuccess) ctx->num_cu = prop.multiProcessorCount; }
+    if (e == hipSuccess) e = hipEventCreate(&ctx->ev0);
+    if (e == hipSuccess) e = hipEventCreate(&ctx->ev1);
+    if (e != hipSuccess) { fail(nullptr, RT_ERR_HIP, "rt_create: %s", hipGetErrorString(e)); rt_destroy(ctx); return RT_ERR_HIP; }
+    *out = ctx;
+    return RT_OK;
+}
+
+void rt_destroy(rt_context* ctx)
+{
+    if (!ctx) return;
+    (void)hipSetDevice(ctx->device);
+    if (ctx->pending) (void)hipStreamSynchronize(ctx->last_stream);
+    (void)hipFree(ctx->d_geom); (void)hipFree(ctx->d_mat); (void)hipFree(ctx->d_aux); (void)hipFree(ctx->d_rays); (void)hipFree(ctx->d_ppm_scratch); (void)hipFree(ctx->d_out_rgb); (void)hipFree(ctx->d_out_irgb);
+    (void)hipFree(ctx->d_bvh_nodes); (void)hipFree(ctx->d_bvh_leaf); (void)hipFree(ctx->d_bvh_big);
+    (void)hipFree(ctx->d_frec); (void)hipFree(ctx->d_prec); (void)hipFree(ctx->d_samples); (void)hipFree(ctx->d_accum); (void)hipFree(ctx->d_work); (void)hipFree(ctx->d_stacks); (void)hipFree(ctx->d_staging); (void)hipFree(ctx->d_tile_cls); (void)hipFree(ctx->d_tile_order);
+    (void)hipFree(ctx->wf_ray); (void)hipFree(ctx->wf_pixsmp); (void)hipFree(ctx->wf_depth); (void)hipFree(ctx->wf_hit_t); (void)hipFree(ctx->wf_hit_idx);
+    (void)hipFree(ctx->wf_stacks); (void)hipFree(ctx->wf_q[0]); (void)hipFree(ctx->wf_q[1]); (void)hipFree(ctx->wf_n);
+    if (ctx->ev0) (void)hipEventDestroy(ctx->ev0);
+    if (ctx->ev1) (void)hipEventDestroy(ctx->ev1);
+    delete ctx;
+}
+
+const char* rt_last_error(const rt_context* ctx) { return ctx ? ctx->error.c_str() : g_error.c_str(); }
+
+int rt_upload_scene(rt_context* ctx, int n, const float* cx, const float* cy, const float* cz, const float* radius,
+                    const int32_t* material, const float* albedo_rgb, const float* param)
+{
+    if (!ctx) return fail(nullptr, RT_ERR_INVALID, "rt_upload_scene: null context");
+    if (n <= 0 || !cx || !cy || !cz || !radius || !material || !albedo_rgb || !param) return fail(ctx, RT_ERR_INVALID, "rt_upload_scene: null array or n <= 0");
+    if (n > 65535) return fail(ctx, RT_ERR_TOO_LARGE, "rt_upload_scene: %d spheres exceeds the 65535 limit of the 16-bit hit stack", n);
+    std::vector<float4> geom(n), mat(n); std::vector<Aux> aux(n);
+    const int n_pad = (n + 7) / 8 * 8;
+    // Filter records (cx, cy, cz, k), k = |c|^2 - r^2 - slack_i.  With u = 2^-24, M = |o| + |c| and the
+    // ray direction normalised, the filter's own rounding error is below 32 u M^2 and the reference's
+    // discriminant (divided by |d|^2) is off by less than 32 u (|o - c|^2 + r^2); since
+    // M^2 <= 2 (|o|^2 + |c|^2), slack_i = 160 u |c|^2 + 48 u r^2 here plus 160 u |o|^2 per ray in the
+    // kernel makes "filter negative" imply "reference discriminant not positive".
+    std::vector<float4> frec(n_pad, make_float4(0.0f, 0.0f, 0.0f, FLT_MAX));
+    for (int i = 0; i < n; ++i) {
+        const double cc = (double)cx[i] * cx[i] + (double)cy[i] * cy[i] + (double)cz[i] * cz[i], rr = (double)radius[i] * radius[i];
+        const double k = cc - rr - 5.9604644775390625e-08 * (160.0 * cc + 48.0 * rr);
+        float kf = (float)k;
+        if ((double)kf > k) kf = nextafterf(kf, -INFINITY);
+        frec[i] = make_float4(cx[i], cy[i], cz[i], kf);
+    }
+    // Plane-filter records (cx, cz, R_i = r^2 + slack_i, 0).  u = 2^-24.  Allowance for the reference's own
+    // discriminant rounding: 32 u (|o-c|^2 + r^2) <= 64 u (|o|^2 + |c|^2) + 32 u r^2; this form's rounding
+    // of pu (< 8 u (|c| + |o|)) moves pu^2 near the threshold by < 16 u |r| (|c| + |o|)
+    // <= 8 u (2 r^2 + |c|^2 + |o|^2).  slack_i = u (128 |c|^2 + 64 r^2), S_ray = 128 u |o|^2 (kernel).
+    std::vector<float4> prec(n_pad, make_float4(0.0f, 0.0f, -FLT_MAX, 0.0f));
+    double rmin_R = 1e30;
+    for (int i = 0; i < n; ++i) {
+        const double rr = (double)radius[i] * radius[i];
+        const double cc = (double)cx[i] * cx[i] + (double)cy[i] * cy[i] + (double)cz[i] * cz[i];
+        const double R = rr + 5.9604644775390625e-08 * (128.0 * cc + 64.0 * rr) + 1e-30;
+        float rf = (float)R; if ((double)rf < R) rf = nextafterf(rf, INFINITY);
+        prec[i] = make_float4(cx[i], cz[i], rr > 1e-12 ? rf : FLT_MAX, 0.0f);     // zero-radius spheres always go to the exact test
+        if (rr > 1e-12 && (double)rf < rmin_R) rmin_R = (double)rf;
+    }
+    const float plane_s0 = 1e-30f;
+    if (rmin_R > 1e29) rmin_R = 1.0;
+    const float plane_rmin = nextafterf((float)rmin_R, 0.0f);
+    for (int i = 0; i < n; ++i) {
+        if (material[i] < RT_LAMBERTIAN || material[i] > RT_DIELECTRIC) return fail(ctx, RT_ERR_INVALID, "rt_upload_scene: sphere %d has unknown material %d", i, material[i]);
+        geom[i] = make_float4(cx[i], cy[i], cz[i], radius[i] * radius[i]);
+        const bool glass = material[i] == RT_DIELECTRIC;   // Dielectric::Scatter sets attenuation (1,1,1)
+        mat[i] = make_float4(glass ? 1.0f : albedo_rgb[3 * i], glass ? 1.0f : albedo_rgb[3 * i + 1], glass ? 1.0f : albedo_rgb[3 * i + 2], param[i]);
+        aux[i].radius = radius[i]; aux[i].type = material[i];
+    }
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    if (ctx->pending) { HIP_TRY(ctx, hipStreamSynchronize(ctx->last_stream)); ctx->pending = false; }
+    (void)hipFree(ctx->d_geom); (void)hipFree(ctx->d_mat); (void)hipFree(ctx->d_aux); (void)hipFree(ctx->d_frec); (void)hipFree(ctx->d_prec);
+    ctx->d_geom = nullptr; ctx->d_mat = nullptr; ctx->d_aux = nullptr; ctx->d_frec = nullptr; ctx->d_prec = nullptr; ctx->n = 0;
+    HIP_TRY(ctx, hipMalloc(&ctx->d_prec, sizeof(float4) * n_pad));
+    HIP_TRY(ctx, hipMemcpy(ctx->d_prec, prec.data(), sizeof(float4) * n_pad, hipMemcpyHostToDevice));
+    ctx->plane_s0 = plane_s0; ctx->plane_rmin = plane_rmin;
+    HIP_TRY(ctx, hipMalloc(&ctx->d_frec, sizeof(float4) * n_pad));
+    HIP_TRY(ctx, hipMemcpy(ctx->d_frec, frec.data(), sizeof(float4) * n_pad, hipMemcpyHostToDevice));
+    ctx->n_pad = n_pad;
+    // n_pad entries: a ray with a NaN direction passes every filter record, padding included, and the exact pass
+    // then reads geom[k] for k up to n_pad - 1 (the NaN discriminant rejects it)
+    HIP_TRY(ctx, hipMalloc(&ctx->d_geom, sizeof(float4) * n_pad));
+    HIP_TRY(ctx, hipMemset(ctx->d_geom, 0, sizeof(float4) * n_pad));
+    HIP_TRY(ctx, hipMalloc(&ctx->d_mat, sizeof(float4) * n));
+    HIP_TRY(ctx, hipMalloc(&ctx->d_aux, sizeof(Aux) * n));
+    HIP_TRY(ctx, hipMemcpy(ctx->d_geom, geom.data(), sizeof(float4) * n, hipMemcpyHostToDevice));
+    HIP_TRY(ctx, hipMemcpy(ctx->d_mat, mat.data(), sizeof(float4) * n, hipMemcpyHostToDevice));
+    HIP_TRY(ctx, hipMemcpy(ctx->d_aux, aux.data(), sizeof(Aux) * n, hipMemcpyHostToDevice));
+    {
+        BvhHost tree;
+        if (!build_bvh(n, cx, cy, cz, radius, &tree)) return fail(ctx, RT_ERR_TOO_LARGE, "rt_upload_scene: sphere hierarchy deeper than %d levels", kBvhStack - 2);
+        (void)hipFree(ctx->d_bvh_nodes); (void)hipFree(ctx->d_bvh_leaf); (void)hipFree(ctx->d_bvh_big);
+        ctx->d_bvh_nodes = nullptr; ctx->d_bvh_leaf = nullptr; ctx->d_bvh_big = nullptr;
+        HIP_TRY(ctx, hipMalloc(&ctx->d_bvh_nodes, sizeof(float4) * tree.nodes.size()));
+        HIP_TRY(ctx, hipMemcpy(ctx->d_bvh_nodes, tree.nodes.data(), sizeof(float4) * tree.nodes.size(), hipMemcpyHostToDevice));
+        HIP_TRY(ctx, hipMalloc(&ctx->d_bvh_leaf, sizeof(uint32_t) * tree.leaf_index.size()));
+        HIP_TRY(ctx, hipMemcpy(ctx->d_bvh_leaf, tree.leaf_index.data(), sizeof(uint32_t) * tree.leaf_index.size(), hipMemcpyHostToDevice));
+        HIP_TRY(ctx, hipMalloc(&ctx->d_bvh_big, sizeof(uint32_t) * (tree.big.size() + 1)));
+        if (!tree.big.empty()) HIP_TRY(ctx, hipMemcpy(ctx->d_bvh_big, tree.big.data(), sizeof(uint32_t) * tree.big.size(), hipMemcpyHostToDevice));
+        ctx->bvh_n_big = (int)tree.big.size(); ctx->bvh_depth = tree.depth; ctx->bvh_nodes = tree.node_count();
+    }
+    ctx->n = n; ++ctx->scene_version;
+    return RT_OK;
+}
+
+int rt_set_camera(rt_context* ctx, const rt_camera_pod* cam)
+{
+    if (!ctx) return fail(nullptr, RT_ERR_INVALID, "rt_set_camera: null context");
+    if (!cam) return fail(ctx, RT_ERR_INVALID, "rt_set_camera: null camera");
+    ctx->cam = to_device(*cam);
+    ctx->have_camera = true; ++ctx->camera_version;
+    return RT_OK;
+}
+
+int64_t rt_owned_rows(const rt_params* p)
+{
+    if (!params_ok(p)) return 0;
+    const int64_t nbands = ((int64_t)p->height + p->band_rows - 1) / p->band_rows;
+    int64_t rows = 0;
+    for (int64_t b = p->band_first; b < nbands; b += p->band_step) {
+        const int64_t y0 = b * p->band_rows, y1 = y0 + p->band_rows;
+        rows += (y1 < p->height ? y1 : p->height) - y0;
+    }
+    return rows;
+}
+
+int64_t rt_owned_pixels(const rt_params* p) { return rt_owned_rows(p) * (p ? p->width : 0); }
+
+int rt_render_device(rt_context* ctx, const rt_params* p, float* d_rgb_mean, int32_t* d_irgb, void* stream)
+{
+    if (!ctx) return fail(nullptr, RT_ERR_INVALID, "rt_render_device: null context");
+    if (!params_ok(p)) return fail(ctx, RT_ERR_INVALID, "rt_render_device: invalid parameters");
+    if (!ctx->n || !ctx->have_camera) return fail(ctx, RT_ERR_STATE, "rt_render_device: scene and camera must be set first");
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    const int owned = (int)rt_owned_rows(p);
+    HIP_TRY(ctx, hipMemsetAsync(ctx->d_rays, 0, 2 * sizeof(unsigned long long), st));
+    HIP_TRY(ctx, hipEventRecord(ctx->ev0, st));
+    if (owned > 0) {
+        RenderFrame f{};
+        f.p = p; f.owned = owned; f.d_rgb_mean = d_rgb_mean; f.d_irgb = d_irgb; f.st = st;
+        if (p->mode == RT_MODE_PIXEL) {
+            const int rc = pixel_render(ctx, f);
+            if (rc != RT_OK) return rc;
+        } else {
+            f.tiles_x = (p->width + 7) / 8;
+            f.Q = (uint64_t)f.tiles_x * ((owned + 7) / 8) * 64;
+            // sample batches: the per-batch sample buffer stays below 16 GiB (of 288 GB of HBM) and item ids below 2^31;
+            // every batch ends with the drain of its longest paths, so fewer, larger batches are better
+            uint64_t per_batch = ctx->sample_buffer_cap / (f.Q * 12);
+            if (per_batch > (1ull << 31) / f.Q) per_batch = (1ull << 31) / f.Q;
+            if (per_batch == 0) return fail(ctx, RT_ERR_TOO_LARGE, "rt_render_device: %llu pixels in one call exceed the sample-buffer limit; split the image into bands", (unsigned long long)f.Q);
+            f.batches = (int)((p->spp + per_batch - 1) / per_batch);
+            f.s_per = (p->spp + f.batches - 1) / f.batches;
+            const size_t need = (size_t)f.Q * f.s_per * 12;
+            if (ctx->samples_bytes < need) {
+                HIP_TRY(ctx, hipStreamSynchronize(st));
+                (void)hipFree(ctx->d_samples); ctx->d_samples = nullptr; ctx->samples_bytes = 0;
+                HIP_TRY(ctx, hipMalloc(&ctx->d_samples, need)); ctx->samples_bytes = need;
+            }
+            if (f.batches > 1 && ctx->accum_bytes < f.Q * 12) {
+                HIP_TRY(ctx, hipStreamSynchronize(st));
+                (void)hipFree(ctx->d_accum); ctx->d_accum = nullptr; ctx->accum_bytes = 0;
+                HIP_TRY(ctx, hipMalloc(&ctx->d_accum, f.Q * 12)); ctx->accum_bytes = f.Q * 12;
+            }
+            const bool wavefront = p->mode == RT_MODE_WAVEFRONT;
+            TracePlan plan{};
+            if (!wavefront) { const int rc = trace_prepare(ctx, f, &plan); if (rc != RT_OK) return rc; }
+            for (int bi = 0, s0 = 0; bi < f.batches; ++bi, s0 += f.s_per) {
+                const SampleBatch b{ bi, s0, (p->spp - s0 < f.s_per) ? p->spp - s0 : f.s_per };
+                int rc = wavefront ? wavefront_batch(ctx, f, b) : trace_batch(ctx, f, plan, b);
+                if (rc == RT_OK) rc = resolve_batch(ctx, f, b);
+                if (rc != RT_OK) return rc;
+            }
+        }
+    }
+    HIP_TRY(ctx, hipEventRecord(ctx->ev1, st));
+    ctx->last_stream = st; ctx->pending = true; ctx->last_samples = (uint64_t)rt_owned_pixels(p) * (uint64_t)p->spp;
+    return RT_OK;
+}
+
+int rt_render_stats(rt_context* ctx, uint64_t* rays, float* kernel_ms)
+{
+    if (!ctx) return fail(nullptr, RT_ERR_INVALID, "rt_render_stats: null context");
+    if (!ctx->pending) return fail(ctx, RT_ERR_STATE, "rt_render_stats: no render has been enqueued");
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    HIP_TRY(ctx, hipEventSynchronize(ctx->ev1));
+    if (kernel_ms) HIP_TRY(ctx, hipEventElapsedTime(kernel_ms, ctx->ev0, ctx->ev1));
+    if (rays) {
+        unsigned long long r = 0;
+        HIP_TRY(ctx, hipMemcpyAsync(&r, ctx->d_rays, sizeof r, hipMemcpyDeviceToHost, ctx->last_stream));
+        HIP_TRY(ctx, hipStreamSynchronize(ctx->last_stream));
+        *rays = r;
+    }
+    return RT_OK;
+}
+
+int rt_render_counters(rt_context* ctx, rt_counters* out)
+{
+    if (!ctx) return fail(nullptr, RT_ERR_INVALID, "rt_render_counters: null context");
+    if (!out) return fail(ctx, RT_ERR_INVALID, "rt_render_counters: null output");
+    if (!ctx->pending) return fail(ctx, RT_ERR_STATE, "rt_render_counters: no render has been enqueued");
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    unsigned long long c[2] = { 0, 0 };
+    HIP_TRY(ctx, hipMemcpyAsync(c, ctx->d_rays, sizeof c, hipMemcpyDeviceToHost, ctx->last_stream));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->last_stream));
+    out->rays_traced = c[0];
+    out->intersection_tests = c[0] - c[1];
+    // every Color() call beyond the first of a sample was made by a successful Scatter below the depth cap
+    out->material_evaluations = c[0] - ctx->last_samples;
+    return RT_OK;
+}
+
+int rt_render(rt_context* ctx, const rt_params* p, float* h_rgb_mean, int32_t* h_irgb, uint64_t* rays, float* kernel_ms)
+{
+    if (!ctx) return fail(nullptr, RT_ERR_INVALID, "rt_render: null context");
+    if (!params_ok(p)) return fail(ctx, RT_ERR_INVALID, "rt_render: invalid parameters");
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    const size_t npx = (size_t)rt_owned_pixels(p);
+    float* d_rgb = nullptr; int32_t* d_i = nullptr;
+    // The device side of the host outputs is kept in the context between calls (band-by-band callers make
+    // many small calls; an allocation and a free per call cost more than the band's kernels).
+    if (h_rgb_mean && npx) {
+        const size_t need = npx * 3 * sizeof(float);
+        if (ctx->out_rgb_bytes < need) {
+            (void)hipFree(ctx->d_out_rgb); ctx->d_out_rgb = nullptr; ctx->out_rgb_bytes = 0;
+            HIP_TRY(ctx, hipMalloc(&ctx->d_out_rgb, need)); ctx->out_rgb_bytes = need;
+        }
+        d_rgb = ctx->d_out_rgb;
+    }
+    if (h_irgb && npx) {
+        const size_t need = npx * 3 * sizeof(int32_t);
+        if (ctx->out_irgb_bytes < need) {
+            (void)hipFree(ctx->d_out_irgb); ctx->d_out_irgb = nullptr; ctx->out_irgb_bytes = 0;
+            HIP_TRY(ctx, hipMalloc(&ctx->d_out_irgb, need)); ctx->out_irgb_bytes = need;
+        }
+        d_i = ctx->d_out_irgb;
+    }
+    int rc = rt_render_device(ctx, p, d_rgb, d_i, nullptr);
+    if (rc == RT_OK) rc = rt_render_stats(ctx, rays, kernel_ms);
+    if (rc == RT_OK && d_rgb) { hipError_t e = hipMemcpy(h_rgb_mean, d_rgb, npx * 3 * sizeof(float), hipMemcpyDeviceToHost); if (e != hipSuccess) rc = fail(ctx, RT_ERR_HIP, "rt_render: copy back: %s", hipGetErrorString(e)); }
+    if (rc == RT_OK && d_i) { hipError_t e = hipMemcpy(h_irgb, d_i, npx * 3 * sizeof(int32_t), hipMemcpyDeviceToHost); if (e != hipSuccess) rc = fail(ctx, RT_ERR_HIP, "rt_render: copy back: %s", hipGetErrorString(e)); }
+    return rc;
+}
+
+}  // extern "C"

@@ -53,6 +53,24 @@ struct rt_context {
 int fail(rt_context* ctx, int code, const char* fmt, ...) __attribute__((format(printf, 3, 4), visibility("hidden")));
 #define HIP_TRY(ctx, call) do { hipError_t e_ = (call); if (e_ != hipSuccess) return fail(ctx, RT_ERR_HIP, "%s failed: %s", #call, hipGetErrorString(e_)); } while (0)
 
+// One rt_render_device call as the kernels' launchers see it.  The image is numbered in 8x8 pixel tiles; Q is the padded
+// pixel count (tiles x 64); samples are rendered in `batches` batches of at most s_per samples per pixel.
+struct RenderFrame {
+    const rt_params* p; int owned;
+    int tiles_x; uint64_t Q; int batches, s_per;
+    float* d_rgb_mean; int32_t* d_irgb; hipStream_t st;
+};
+struct SampleBatch { int index, s0, sc; };
+// What trace_prepare settles once per call for the batches of k_trace.
+struct TracePlan { bool lds, plane, bvh, reclds, ordered; size_t shmem; int blocks_per_cu; };
+
+#define RT_HIDDEN __attribute__((visibility("hidden")))
+int pixel_render(rt_context* ctx, const RenderFrame& f) RT_HIDDEN;                                              // rt_pixel.hip
+int trace_prepare(rt_context* ctx, const RenderFrame& f, TracePlan* plan) RT_HIDDEN;                            // rt_trace.hip
+int trace_batch(rt_context* ctx, const RenderFrame& f, const TracePlan& plan, const SampleBatch& b) RT_HIDDEN;  // rt_trace.hip
+int resolve_batch(rt_context* ctx, const RenderFrame& f, const SampleBatch& b) RT_HIDDEN;                       // rt_trace.hip
+int wavefront_batch(rt_context* ctx, const RenderFrame& f, const SampleBatch& b) RT_HIDDEN;                     // rt_wavefront.hip
+
 inline CameraD to_device(const rt_camera_pod& c)
 {
     CameraD d;

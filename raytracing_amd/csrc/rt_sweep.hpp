@@ -1,0 +1,486 @@
+// Device code shared by the render kernels of librt_amd.so (rt_pixel.hip, rt_trace.hip, rt_wavefront.hip): camera rays,
+// the closest-hit sweep in its three forms (all lanes busy, few lanes left, hierarchy walk), one bounce of Color(), and
+// the numbering of work items.  Everything is forceinline; every translation unit gets its own copy.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <cfloat>
+#include <cstdint>
+#include "rt_internal.hpp"
+#include "rt_bvh.hpp"
+
+// ============================================================================ device data layout
+// Scene records in HBM (built once per upload) and, for the megakernel, mirrored into LDS:
+//   geom[i] = (cx, cy, cz, r*r)       16 B  -- everything the sweep touches
+//   mat[i]  = (ar, ag, ab, param)     16 B  -- read once per hit
+//   aux[i]  = (radius, type)           8 B  -- read once per hit (normal = (p - c) / radius)
+
+
+static constexpr int kBlock = 256;          // 4 waves; each wave owns an 8x8 pixel tile
+static constexpr int kLdsBytesPerSphere = 40;
+static constexpr int kMaxLdsSpheres = 1536; // 60 KB of LDS per block -> at least two blocks per CU
+
+// Compact owned row r -> image row y (from the top).
+__device__ __forceinline__ int owned_row_to_y2(int band_rows, int band_first, int band_step, int r)
+{
+    const int k = r / band_rows;
+    return (band_first + k * band_step) * band_rows + (r - k * band_rows);
+}
+
+// Camera ray of (pixel, sample): jitter from words 0,1 of group 0 (main.cpp:126-127), lens sample by
+// rejection from the words lens_words() names, then Camera::GetRay (camera.cpp:46-53).
+__device__ __forceinline__ RayD camera_ray(const CameraD& cam, uint32_t pix, uint32_t smp, int i, int j, float fnx, float fny, uint32_t k0, uint32_t k1)
+{
+    U4 blk = philox4x32_10(pix, smp, 0u, 0u, k0, k1);
+    const float fu = (float)((double)i + (double)u01(blk.x)) / fnx;
+    const float fv = (float)((double)j + (double)u01(blk.y)) / fny;
+    float dx = 0.0f, dy = 0.0f;
+    if (cam.lens_radius > 0.0f) {
+        uint32_t t = 0;
+        for (;;) {
+            float a, b;
+            lens_words(blk, t, a, b);
+            dx = 2.0f * a - 1.0f; dy = 2.0f * b - 1.0f;
+            if (!((dx * dx) + (dy * dy) + 0.0f >= 1.0f)) break;
+            ++t;
+            if (t & 1u) blk = philox4x32_10(pix, smp, 0u, (t + 1u) >> 1, k0, k1);
+        }
+    }
+    return get_ray(cam, fu, fv, dx, dy);
+}
+
+// Device view of the sphere hierarchy (rt_bvh.hpp) for RT_MODE_BVH.
+struct BvhScene {
+    const float4* nodes; const uint32_t* leaf_index; const uint32_t* big; int n_big;
+    const float4* geom;
+};
+
+// Diagnostic build (-DRT_SECTION_TIMERS): every wave accumulates s_memtime ticks per section of the
+// main loop into g_section_ticks.  Never enabled in the shipped library (mark() is empty there).
+#ifdef RT_WAVE_TIMELINE
+// Diagnostic build (-DRT_WAVE_TIMELINE), per wave of the last k_trace launch: s_memrealtime (100 MHz, common to all XCDs) at entry, when the wave first found the work counter dry, at exit;
+// and how many trips of the main loop it made after that point
+static __device__ unsigned long long g_wave_times[8][8192];      // rows 4, 5: trips made with the sparse sweep, ticks spent in those trips (whole trip); 6: first sweep starts; 7: first trip ends
+#endif
+#ifdef RT_SECTION_TIMERS
+static __device__ unsigned long long g_section_ticks[8];
+struct SecTimer {
+    unsigned long long acc[8]; unsigned long long last;
+    __device__ __forceinline__ void start() { for (int k = 0; k < 8; ++k) acc[k] = 0; last = __builtin_amdgcn_s_memtime(); }
+    __device__ __forceinline__ void mark(int idx) { const unsigned long long t = __builtin_amdgcn_s_memtime(); acc[idx] += t - last; last = t; }
+    __device__ __forceinline__ void flush(int lane) { if (lane == 0) for (int k = 0; k < 8; ++k) atomicAdd(&g_section_ticks[k], acc[k]); }
+};
+#else
+struct SecTimer {
+    __device__ __forceinline__ void start() {}
+    __device__ __forceinline__ void mark(int) {}
+    __device__ __forceinline__ void flush(int) {}
+};
+#endif
+static constexpr int kChunkItems = 512;
+static constexpr int kStagingRows = 9;
+static constexpr int kTraceBlock = 512;         // 8 waves share one LDS copy of the scene records
+__device__ __forceinline__ float staged_load(const float* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+static constexpr int kSuperChunkWords = 16;                     // 32-sphere mask words kept per lane between exact passes (512 spheres)
+static constexpr float kRaySlack = 160.0f * 5.9604645e-08f;   // per-ray slack, relative to |o|^2
+static constexpr float kPlaneRaySlack = 128.0f * 5.9604645e-08f;
+
+// ============================================================================ closest-hit sweep
+// HittableList::Hit (hittablelist.cpp:13-31) over Sphere::Hit (sphere.cpp:15-52) for one ray per lane,
+// brute force over all spheres, as filter + exact (see k_trace).  Shared by the persistent megakernel and
+// the wavefront intersect kernel.  mask_words: this lane's column of kSuperChunkWords LDS words.
+struct SweepScene {
+    const float4* frec;      // disc-filter records (cx, cy, cz, |c|^2 - r^2 - slack), padded to a multiple of 8
+    const float4* prec;      // plane-filter records (cx, cz, R_i = r^2 + slack_i, 0), same padding
+    float plane_s0;          // constant part of the plane filter's per-ray slack
+    float plane_rmin;        // smallest R_i over the non-degenerate spheres
+    const float4* geom;      // exact records in HBM (used when they are not mirrored in LDS)
+    int n, n_pad;
+};
+
+template <bool kLds, bool kPlane, bool kRecLds>
+__device__ __forceinline__ void closest_hit(const RayD& ray, float tmin, const SweepScene& sw, const float4* s_geom, const float4* s_prec,
+                                            uint32_t* mask_words, float& closest, int& hit, SecTimer& T)
+{
+    // Per ray: unit direction (approximate is enough for a conservative test), -(o.d^), 2o,
+    // -|o|^2 (1 - slack).  Per sphere record (cx, cy, cz, k), k = |c|^2 - r^2 - slack_i:
+    //   b = c.d^ - o.d^            3 FMA      w = 2 o.c - |o|^2'        3 FMA
+    //   e = b*b + w                1 FMA      s = e - k                 1 SUB   -> sign bit
+    // s >= 0 is necessary for the reference's discriminant to be positive.
+    const float qa = dot(ray.d, ray.d);
+    const float rs = __frsqrt_rn(fmaf(ray.d.x, ray.d.x, fmaf(ray.d.y, ray.d.y, ray.d.z * ray.d.z)));
+    const float hx = ray.d.x * rs, hy = ray.d.y * rs, hz = ray.d.z * rs;
+    const float nod = -fmaf(ray.o.x, hx, fmaf(ray.o.y, hy, ray.o.z * hz));
+    const float p2x = 2.0f * ray.o.x, p2y = 2.0f * ray.o.y, p2z = 2.0f * ray.o.z;
+    const float oo = fmaf(ray.o.x, ray.o.x, fmaf(ray.o.y, ray.o.y, ray.o.z * ray.o.z));
+    const float noo = kRaySlack * oo - oo;
+    // Plane filter (kPlane): the vertical plane through the ray has a horizontal normal u perp d, so
+    // the signed distance of a centre to it is pu = cx*ux + cz*uz - o.u (2 FMA).  The reference
+    // accepts a sphere only if its discriminant b^2 - a c is positive, and in its float arithmetic
+    // that can happen for a line passing up to sqrt(r^2 + 32 ulp (|o-c|^2 + r^2)) from the centre,
+    // so the test is pu^2 <= R_i + S_ray with that allowance (and this form's own rounding) split
+    // into a per-sphere part R_i (host) and a per-ray part S_ray.
+    float ux = 1.0f, uz = 0.0f, nou = 0.0f, s_ray = 0.0f;
+    if (kPlane) {
+        const float h2 = fmaf(hx, hx, hz * hz);
+        if (h2 > 1e-12f) { const float ih = __frsqrt_rn(h2); ux = hz * ih; uz = -hx * ih; }
+        // Fold the per-ray allowance S_ray into the normal instead of subtracting it per pair: with
+        // kappa^2 = Rmin / (Rmin + S_ray), (kappa pu)^2 <= R_i holds whenever pu^2 <= R_i + S_ray and
+        // R_i >= Rmin, so the per-pair test is the sign of R_i - pu'^2 alone (3 FMA per pair).
+        s_ray = fmaf(kPlaneRaySlack, oo, sw.plane_s0);
+        const float k2 = sw.plane_rmin / (sw.plane_rmin + s_ray);
+        const float kappa = sqrtf(k2) * (1.0f - 4.0f * 5.9604645e-08f);
+        ux *= kappa; uz *= kappa;
+        nou = -fmaf(ray.o.x, ux, ray.o.z * uz);
+    }
+    // Filter records are read through the constant address space: the index is wave-uniform,
+    // so each record arrives by scalar load in SGPRs and feeds the FMAs as a scalar operand.
+    typedef float f4v __attribute__((ext_vector_type(4)));
+    typedef const __attribute__((address_space(4))) f4v* ConstRec;
+    const ConstRec frec_k = (ConstRec)(sw.frec);
+    const ConstRec prec_k = (ConstRec)(sw.prec);
+
+    // Filter one 32-sphere chunk (or a shorter tail, a multiple of 8): kCount sign bits, left-aligned
+    // (bit 31 = first record of the chunk), 1 = rejected.
+    auto filter_bits = [&](int base, auto count_tag) -> uint32_t {
+        constexpr int kCount = decltype(count_tag)::value;
+        uint32_t mask = 0u;
+#pragma unroll
+        for (int jj = 0; jj < kCount; ++jj) {
+            float sgn;
+            if (kPlane) {
+                float fx, fy, fz;
+                if (kRecLds) { const float4 f = s_prec[base + jj]; fx = f.x; fy = f.y; fz = f.z; }
+                else { const f4v f = prec_k[base + jj]; fx = f.x; fy = f.y; fz = f.z; }
+                const float pu = fmaf(fx, ux, fmaf(fy, uz, nou));
+                sgn = fmaf(-pu, pu, fz);
+            } else {
+                const f4v f = frec_k[base + jj];
+                const float b = fmaf(f.x, hx, fmaf(f.y, hy, fmaf(f.z, hz, nod)));
+                const float w = fmaf(f.x, p2x, fmaf(f.y, p2y, fmaf(f.z, p2z, noo)));
+                const float e = fmaf(b, b, w);
+                sgn = e - f.w;
+            }
+            mask = __builtin_amdgcn_alignbit(mask, __float_as_uint(sgn), 31);   // append sign bit
+        }
+        return mask;
+    };
+
+    T.mark(1);
+    // Super-chunks of up to 16 mask words (512 spheres).  The filter only stores each word and notes
+    // whether it has a survivor; afterwards one loop per lane walks its surviving bits in ascending
+    // sphere order and runs the exact test of sphere.cpp:15-52 with the shrinking upper bound of
+    // hittablelist.cpp:21-29 (unfused arithmetic).
+    for (int sbase = 0; sbase < sw.n_pad; sbase += 32 * kSuperChunkWords) {
+        uint32_t nz = 0u;          // bit (31 - w) set: word w of this super-chunk has a survivor
+        int words = 0;
+        int base = sbase;
+        const int send = (sw.n_pad - sbase < 32 * kSuperChunkWords) ? sw.n_pad : sbase + 32 * kSuperChunkWords;
+        for (; base + 32 <= send; base += 32, ++words) {
+            const uint32_t cand = ~filter_bits(base, std::integral_constant<int, 32>());
+            mask_words[words * 64] = cand;
+            nz = __builtin_amdgcn_alignbit(nz, cand | (0u - cand), 31);
+        }
+        if (base < send) {         // tail: 8, 16 or 24 records
+            uint32_t m = 0u; int got = 0;
+            for (; base < send; base += 8, got += 8) m = (m << 8) | filter_bits(base, std::integral_constant<int, 8>());
+            const uint32_t cand = (~m) << (32 - got);
+            mask_words[words * 64] = cand;
+            nz = __builtin_amdgcn_alignbit(nz, cand | (0u - cand), 31);
+            ++words;
+        }
+        nz <<= (32 - words);
+        T.mark(1);
+        // Pass A: exact discriminant of every survivor of the filter (sphere.cpp:17-25); the bits of
+        // those with desc <= 0 are cleared in place.  Pass B: roots, range test and running minimum
+        // (sphere.cpp:27-50, hittablelist.cpp:21-29) for what is left, in ascending index order.
+        // Splitting keeps the square root and the two divisions out of the long first loop, where
+        // some lane of the wave would otherwise need them on every trip.
+        // Every word flagged in nz is non-zero, and padding records never pass the filter, so each bit
+        // visited names a real sphere (k < n).
+        uint32_t nzb = 0u;
+        if (nz != 0u) {
+            int w = __builtin_clz(nz);
+            nz &= ~(0x80000000u >> w);
+            uint32_t cand = mask_words[w * 64], keep = 0u;
+            int cbase = sbase + (w << 5);
+            for (;;) {
+                const int jj = __builtin_clz(cand);
+                const uint32_t bit = 0x80000000u >> jj;
+                cand &= ~bit;
+                const int k = cbase + jj;
+                const float4 g = kLds ? s_geom[k] : sw.geom[k];
+                const V3 oc = ray.o - mk(g.x, g.y, g.z);
+                const float b = dot(oc, ray.d);
+                const float cc = dot(oc, oc) - g.w;
+                const float desc = b * b - qa * cc;
+                if (desc > 0.0f) keep |= bit;
+                if (cand == 0u) {
+                    mask_words[w * 64] = keep;
+                    nzb |= keep ? 0x80000000u >> w : 0u;
+                    if (nz == 0u) break;
+                    w = __builtin_clz(nz);
+                    nz &= ~(0x80000000u >> w);
+                    cand = mask_words[w * 64];
+                    keep = 0u;
+                    cbase = sbase + (w << 5);
+                }
+            }
+        }
+        T.mark(2);
+        if (nzb != 0u) {
+            int w = __builtin_clz(nzb);
+            nzb &= ~(0x80000000u >> w);
+            uint32_t cand = mask_words[w * 64];
+            int cbase = sbase + (w << 5);
+            for (;;) {
+                const int jj = __builtin_clz(cand);
+                cand &= ~(0x80000000u >> jj);
+                const int k = cbase + jj;
+                const float4 g = kLds ? s_geom[k] : sw.geom[k];
+                const V3 oc = ray.o - mk(g.x, g.y, g.z);
+                const float b = dot(oc, ray.d);
+                const float cc = dot(oc, oc) - g.w;
+                const float desc = b * b - qa * cc;
+                const float sq = sqrtf(desc);
+                float temp = (-b - sq) / qa;
+                if (!(temp < closest && temp > tmin)) temp = (-b + sq) / qa;
+                if (temp < closest && temp > tmin) { closest = temp; hit = k; }
+                if (cand == 0u) {
+                    if (nzb == 0u) break;
+                    w = __builtin_clz(nzb);
+                    nzb &= ~(0x80000000u >> w);
+                    cand = mask_words[w * 64];
+                    cbase = sbase + (w << 5);
+                }
+            }
+        }
+        T.mark(3);
+    }
+}
+
+// The same closest-hit query for a wave that holds only a few live paths (the tail of a launch, when the work
+// counter has run dry): instead of one ray per lane and a loop over the spheres, the live rays are taken one
+// at a time and the SPHERES are spread over the 64 lanes (sphere k on lane k mod 64), followed by a wave
+// reduction.  A sweep for a sparse wave costs as many issue slots as one for a full wave, and a lone wave issues
+// slowly, so this shortens the bounces of the last long paths several times over.  The result is the same
+// (sphere, t): HittableList::Hit's answer is the smallest accepted root over all spheres with ties going to the
+// lower index (hittablelist.cpp:21-29 with sphere.cpp:27-50: for one sphere the accepted root under a running
+// bound c is its first root above tmin, if below c), which does not depend on how the spheres are partitioned.
+#ifndef RT_FEW_PATHS
+#define RT_FEW_PATHS 8
+#endif
+// depth of the deepest path a wave holds at which it is raised to issue priority 1, 2, 3 (4/8/16, 2/4/8, 12/20/32 and
+// 16/24/36 measure within the run-to-run spread of this choice, tools/ab_prio.sh)
+#ifndef RT_PRIO_1
+#define RT_PRIO_1 8
+#define RT_PRIO_2 16
+#define RT_PRIO_3 32
+#endif
+constexpr int kFewPaths = RT_FEW_PATHS;     // 2, 4 and 8 measure alike on the 1200x800 final scene at 10 spp, 16 and 24 are 4-6 % slower (tools/ab_few.sh)
+template <bool kLds>
+__device__ __forceinline__ void closest_hit_few(const RayD& ray, float tmin, const SweepScene& sw, const float4* s_geom,
+                                                unsigned long long live, int lane, float& closest, int& hit)
+{
+    while (live != 0ull) {
+        const int src = __builtin_ctzll(live);
+        live &= live - 1ull;
+        RayD r;
+        r.o = mk(__builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, ray.o.x), src)),
+                 __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, ray.o.y), src)),
+                 __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, ray.o.z), src)));
+        r.d = mk(__builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, ray.d.x), src)),
+                 __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, ray.d.y), src)),
+                 __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, ray.d.z), src)));
+        const float qa = dot(r.d, r.d);
+        float best = FLT_MAX; int best_k = -1;
+        for (int base = 0; base < sw.n; base += 64) {
+            const int k = base + lane;
+            float b = 0.0f, desc = -1.0f;
+            if (k < sw.n) {
+                const float4 g = kLds ? s_geom[k] : sw.geom[k];
+                const V3 oc = r.o - mk(g.x, g.y, g.z);
+                b = dot(oc, r.d);
+                const float cc = dot(oc, oc) - g.w;
+                desc = b * b - qa * cc;
+            }
+            if (__any(desc > 0.0f)) {
+                if (desc > 0.0f) {
+                    const float sq = sqrtf(desc);
+                    float temp = (-b - sq) / qa;
+                    if (!(temp < best && temp > tmin)) temp = (-b + sq) / qa;
+                    if (temp < best && temp > tmin) { best = temp; best_k = k; }
+                }
+            }
+        }
+        // wave minimum of (t, index): smaller t wins, equal t goes to the lower index
+        for (int off = 1; off < 64; off <<= 1) {
+            const float ot = __shfl_xor(best, off); const int ok = __shfl_xor(best_k, off);
+            if (ot < best || (ot == best && (unsigned)ok < (unsigned)best_k)) { best = ot; best_k = ok; }
+        }
+        if (lane == src) { closest = best; hit = best_k; }
+    }
+}
+
+// ============================================================================ closest hit through the sphere hierarchy
+// RT_MODE_BVH: the same closest hit as the brute-force sweep, found by walking the hierarchy of rt_bvh.hpp per lane.
+// Every sphere that is tested goes through the reference's own arithmetic (sphere.cpp:15-52); the hierarchy only
+// decides which spheres can be skipped, so the box test has to be conservative against that arithmetic:
+//   * the reference reports a hit when its float discriminant b^2 - a c is positive.  With u = 2^-24, counting the
+//     roundings of sphere.cpp:17-25 (oc: u per component; b: 4 u |oc||d|, so b^2: 9 u a |oc|^2; oc.oc - r^2:
+//     5 u |oc|^2 + 2 u r^2; a: 3 u a; the product a c: a (9 u |oc|^2 + 6 u r^2); the difference: u a |oc|^2), the
+//     computed value is off by less than a (19 u |o - c|^2 + 6 u r^2), so the line may pass up to
+//     sqrt(r^2 + 19 u |o - c|^2 + 6 u r^2) from the centre.  A node's centre box is therefore inflated by
+//     sqrt(rmax^2 + 24 u (D^2 + rmax^2)), D = distance from the ray origin to the farthest corner of the box
+//     (>= |o - c| for every sphere below);
+//   * the slab test's own rounding is covered by a further relative 1e-5 and an absolute 1e-6 (1 + |o| + |box|),
+//     the box's part of which the builder adds to the radius stored in the node.
+// The closest hit over a set of spheres is the smallest accepted root, equal roots going to the lower index
+// (hittablelist.cpp:21-29 keeps the first of equal ones and visits in index order); spheres are met here in
+// tree order, so the tie is resolved explicitly.
+constexpr float kBvhSlack = 24.0f * 5.9604645e-08f;
+
+template <bool kLds>
+__device__ __forceinline__ void bvh_test_sphere(const RayD& ray, float qa, float tmin, const BvhScene& bv, const float4* s_geom, int k, float& closest, int& hit)
+{
+    const float4 g = kLds ? s_geom[k] : bv.geom[k];
+    const V3 oc = ray.o - mk(g.x, g.y, g.z);
+    const float b = dot(oc, ray.d);
+    const float cc = dot(oc, oc) - g.w;
+    const float desc = b * b - qa * cc;
+    if (desc > 0.0f) {
+        const float sq = sqrtf(desc);
+        float temp = (-b - sq) / qa;
+        if (!(temp > tmin)) temp = (-b + sq) / qa;          // the first root above tmin is the one a running bound can accept
+        if (temp > tmin && (temp < closest || (temp == closest && k < hit))) { closest = temp; hit = k; }
+    }
+}
+
+// Conservative ray / inflated-centre-box test of one node (see above).  Returns the entry parameter in t_in.
+__device__ __forceinline__ bool bvh_enter(const RayD& ray, float ix, float iy, float iz, float ray_margin, float t_low, float closest,
+                                          const float4 A, const float4 B, float& t_in)
+{
+    const float fx = fmaxf(fabsf(ray.o.x - A.x), fabsf(ray.o.x - B.x));
+    const float fy = fmaxf(fabsf(ray.o.y - A.y), fabsf(ray.o.y - B.y));
+    const float fz = fmaxf(fabsf(ray.o.z - A.z), fabsf(ray.o.z - B.z));
+    const float far2 = fmaf(fx, fx, fmaf(fy, fy, fz * fz));
+    const float r2 = A.w * A.w;
+    // A.w already carries the node's share of the absolute margin (1e-6 (|cmin| + |cmax|), added by the builder);
+    // the hardware square root (1 ulp) is inside the relative 1e-5
+    const float pad = fmaf(__builtin_amdgcn_sqrtf(fmaf(kBvhSlack, far2 + r2, r2)), 1.00001f, ray_margin);
+    const float ax = (A.x - pad - ray.o.x) * ix, bx = (B.x + pad - ray.o.x) * ix;
+    const float ay = (A.y - pad - ray.o.y) * iy, by = (B.y + pad - ray.o.y) * iy;
+    const float az = (A.z - pad - ray.o.z) * iz, bz = (B.z + pad - ray.o.z) * iz;
+    const float t0 = fmaxf(fmaxf(fminf(ax, bx), fminf(ay, by)), fminf(az, bz));
+    const float t1 = fminf(fminf(fmaxf(ax, bx), fmaxf(ay, by)), fmaxf(az, bz));
+    t_in = t0;
+    return t0 <= t1 && t1 >= t_low && t0 <= closest;          // false for a NaN ray: it hits nothing in the reference either
+}
+
+// pending: this lane's column of kBvhStack LDS words (entry e at pending[e * 64]).  The walk handles the two
+// children of a node together: leaves among them are tested at once, of two inner children the nearer is entered
+// and the other one's child pair is left pending (it is re-examined against the then-current closest hit when popped).
+template <bool kLds>
+__device__ __forceinline__ void closest_hit_bvh(const RayD& ray, float tmin, const BvhScene& bv, const float4* s_geom, uint32_t* pending, float& closest, int& hit)
+{
+    const float qa = dot(ray.d, ray.d);
+    for (int j = 0; j < bv.n_big; ++j) bvh_test_sphere<kLds>(ray, qa, tmin, bv, s_geom, (int)bv.big[j], closest, hit);
+    const float ix = 1.0f / ray.d.x, iy = 1.0f / ray.d.y, iz = 1.0f / ray.d.z;
+    const float omag = 1e-6f * (1.0f + fabsf(ray.o.x) + fabsf(ray.o.y) + fabsf(ray.o.z));     // the ray's share of the absolute margin
+    const float t_low = tmin < 0.0f ? -FLT_MAX : 0.0f;
+    auto test_leaf = [&](int link) {
+        const int code = -(link + 1), first = code >> 3, count = (code & 7) + 1;
+        for (int q = 0; q < count; ++q) bvh_test_sphere<kLds>(ray, qa, tmin, bv, s_geom, (int)bv.leaf_index[first + q], closest, hit);
+    };
+    const int root_link = __float_as_int(bv.nodes[1].w);
+    if (root_link < 0) {                    // at most one leaf in the whole tree
+        float t_in;
+        if (bvh_enter(ray, ix, iy, iz, omag, t_low, closest, bv.nodes[0], bv.nodes[1], t_in)) test_leaf(root_link);
+        return;
+    }
+    int sp = 0; uint32_t pair = (uint32_t)root_link;
+    for (;;) {
+        const float4 A0 = bv.nodes[2u * pair], B0 = bv.nodes[2u * pair + 1u], A1 = bv.nodes[2u * pair + 2u], B1 = bv.nodes[2u * pair + 3u];
+        float t_in0, t_in1;
+        bool in0 = bvh_enter(ray, ix, iy, iz, omag, t_low, closest, A0, B0, t_in0);
+        bool in1 = bvh_enter(ray, ix, iy, iz, omag, t_low, closest, A1, B1, t_in1);
+        const int link0 = __float_as_int(B0.w), link1 = __float_as_int(B1.w);
+        if (in0 && link0 < 0) { test_leaf(link0); in0 = false; }
+        if (in1 && link1 < 0) { test_leaf(link1); in1 = false; }
+        in0 = in0 && t_in0 <= closest;      // the leaves may have brought the closest hit nearer
+        in1 = in1 && t_in1 <= closest;
+        if (in0 && in1) {
+            const bool first0 = t_in0 <= t_in1;
+            pending[sp * 64] = (uint32_t)(first0 ? link1 : link0); ++sp;
+            pair = (uint32_t)(first0 ? link0 : link1);
+            continue;
+        }
+        if (in0) { pair = (uint32_t)link0; continue; }
+        if (in1) { pair = (uint32_t)link1; continue; }
+        if (sp == 0) break;
+        --sp; pair = pending[sp * 64];
+    }
+}
+
+// ============================================================================ shading step of Color()
+// One level of the recursion main.cpp:13-39 for a ray whose closest hit is known.  Returns true when the
+// path has ended (sample = its radiance); otherwise ray/depth are advanced and the hit index is pushed on
+// the lane's stack (element k at stack[k * sstride]).
+template <bool kLds>
+__device__ __forceinline__ bool shade_step(RayD& ray, int& depth, float closest, int hit, uint32_t pix, uint32_t smp, int max_depth,
+                                           KeyedUniforms& U, const float4* s_geom, const float4* s_mat, const Aux* s_aux,
+                                           const float4* g_geom, const float4* g_mat, const Aux* g_aux,
+                                           uint16_t* stack, size_t sstride, V3& sample, SecTimer& T)
+{
+    sample = mk(0.0f, 0.0f, 0.0f);
+    bool done = true;
+    if (hit >= 0) {
+        const float4 g = kLds ? s_geom[hit] : g_geom[hit];
+        const float4 m = kLds ? s_mat[hit] : g_mat[hit];
+        const Aux x = kLds ? s_aux[hit] : g_aux[hit];
+        const V3 p = ray.o + closest * ray.d;
+        const V3 nrm = (p - mk(g.x, g.y, g.z)) / x.radius;
+        T.mark(5);
+        if (depth < max_depth) {
+            V3 att; RayD out;
+            U.slot(pix, smp, (uint32_t)depth + 1u);
+            if (scatter(x.type, mk(m.x, m.y, m.z), m.w, ray, p, nrm, U, att, out)) {
+                stack[(size_t)depth * sstride] = (uint16_t)hit; ++depth; ray = out; done = false;
+            }
+        }
+        T.mark(6);
+    } else {
+        sample = sky(ray.d);
+        for (int k = depth - 1; k >= 0; --k) {
+            const int h = stack[(size_t)k * sstride];
+            const float4 m = kLds ? s_mat[h] : g_mat[h];
+            sample = mk(m.x, m.y, m.z) * sample;
+        }
+    }
+    return done;
+}
+
+// Work item -> (pixel key, sample, pixel coordinates).  Items are numbered tile by tile, then sample by
+// sample, then pixel by pixel inside the 8x8 tile: item = (tile * s_count + s_rel) * 64 + row_in_tile * 8 +
+// col_in_tile, so 512 consecutive items are eight samples of ONE tile.  Returns false for the padding pixels
+// of edge tiles.
+//
+// tile_order (optional) is a permutation of the tiles: work position `tile` is image tile tile_order[tile], so
+// that the order in which tiles are WORKED on can differ from where their samples are STORED.  `store` is the
+// item number in image-tile order, i.e. the slot of the sample buffer.
+struct ItemGeometry { int width, height, band_rows, band_first, band_step, owned_rows, tiles_x; uint32_t Q; int s_begin, s_count; const uint32_t* tile_order; };
+__device__ __forceinline__ bool decode_item(const ItemGeometry& ig, uint32_t item, uint32_t& pix, uint32_t& smp, int& i, int& j, uint32_t& store)
+{
+    const uint32_t ts = item >> 6, l = item & 63u;
+    const uint32_t work_tile = ts / (uint32_t)ig.s_count, s_rel = ts - work_tile * (uint32_t)ig.s_count;
+    const uint32_t tile = ig.tile_order ? ig.tile_order[work_tile] : work_tile;
+    store = ((tile * (uint32_t)ig.s_count + s_rel) << 6) + l;
+    const int ty = (int)(tile / (uint32_t)ig.tiles_x), tx = (int)(tile - (uint32_t)ty * (uint32_t)ig.tiles_x);
+    i = tx * 8 + (int)(l & 7u);
+    const int r = ty * 8 + (int)(l >> 3);
+    const int y = owned_row_to_y2(ig.band_rows, ig.band_first, ig.band_step, r < ig.owned_rows ? r : 0);
+    if (!(i < ig.width && r < ig.owned_rows && y < ig.height)) return false;
+    j = ig.height - 1 - y;
+    pix = (uint32_t)j * (uint32_t)ig.width + (uint32_t)i;
+    smp = (uint32_t)ig.s_begin + s_rel;
+    return true;
+}

@@ -1,0 +1,461 @@
+// RT_MODE_MEGAKERNEL and RT_MODE_BVH: the persistent kernel k_trace, the work order of its tiles, and the ordered
+// per-pixel sum k_resolve (shared with the wavefront mode).
+#include "rt_sweep.hpp"
+
+// ============================================================================ persistent megakernel
+// Work item = one sample of one pixel.  Items are numbered tile by tile over 8x8 pixel tiles,
+//   item = (tile * s_count + s_rel) * 64 + (row_in_tile * 8 + col_in_tile),
+// so the 64 items a fresh wave picks up are one tile at one sample (coherent primary rays) and
+// both this kernel's stores and the resolve kernel's loads of the sample buffer are coalesced.
+// A wave draws items from a chunk it reserves with one atomic on a global counter; whenever a
+// lane's path ends it is handed the next item (ballot + prefix count), so every trip of the main
+// loop runs one closest-hit sweep with all lanes busy until the work runs out.
+//
+// The sweep (closest_hit) is split in two:
+//   filter  (hot, branch-free, records as scalar operands): a conservative sign test per ray-sphere
+//            pair -- by default the distance of the centre to the vertical plane through the ray
+//            (3 FMAs), alternatively the whole discriminant expanded about the world origin (8 FMAs) --
+//            with a per-sphere and per-ray slack that dominates every rounding error of both this
+//            form and the reference's.  The sign bits of 32 spheres are shifted into one register.
+//   exact   (cold): the few spheres whose bit says "maybe" are evaluated with the reference's own
+//            unfused arithmetic (sphere.cpp:15-52); the accepted root of each and the running minimum
+//            follow hittablelist.cpp:13-31, so the chosen sphere and t are bit-identical.
+// A wave left with only a few live paths (the end of a launch) switches to closest_hit_few.
+struct TraceArgs {
+    const float4* prec;      // plane-filter records (cx, cz, R_i = r^2 + slack_i, 0), same padding as frec
+    float plane_s0, plane_rmin;   // plane filter: constant part of the per-ray slack, smallest R_i
+    const float4* frec;      // discriminant-filter records (cx, cy, cz, |c|^2 - r^2 - slack), padded to a multiple of 8
+    const float4* geom; const float4* mat; const Aux* aux; int n, n_pad;
+    CameraD cam;
+    int width, height, max_depth; float tmin;
+    uint32_t k0, k1;
+    int band_rows, band_first, band_step, owned_rows;
+    int tiles_x; uint32_t Q;              // padded pixel count = tiles * 64
+    int s_begin, s_count;                 // sample batch
+    uint32_t total_items;                 // Q * s_count  (< 2^31)
+    int chunk_items;                      // items a wave reserves per atomic: a multiple of 64, at most kChunkItems
+    uint32_t resident_waves;              // waves of this launch that run at the same time
+    uint32_t min_chunk_items;             // smallest chunk taken near the end of the work (a multiple of 64)
+    float* samples;                       // [total_items][3]
+    unsigned long long* ray_counter;
+    unsigned int* work_counter;
+    float* staging;                       // per wave: kStagingRows rows (o, d, pixel, sample, sample-buffer slot) of kChunkItems pre-generated camera rays
+    const uint32_t* tile_order;           // work order of the tiles (see decode_item); may be null
+    BvhScene bvh;                         // RT_MODE_BVH only
+    uint16_t* stacks; uint32_t stack_stride;   // hit-index stacks in HBM: entry k of lane g at stacks[k * stack_stride + g]
+};
+
+// ============================================================================ work order of the tiles
+// A persistent wave keeps all its lanes busy only while there are items left to hand out; once the counter
+// runs dry every wave drains the paths it still holds, and a wave with one 50-bounce path left costs as many
+// issue slots per bounce as a full one.  What is in flight at that moment is whatever was started LAST, so
+// tiles are worked on in order of how long their paths can get: tiles that show a metal or glass sphere
+// first, tiles that show only diffuse spheres next, tiles where every probe ray leaves the scene (one ray per
+// sample) last.  The order changes scheduling only: a sample's value and its slot in the sample buffer
+// depend on the image tile, not on when it is traced.
+struct TileArgs {
+    const float4* geom; const Aux* aux; int n;
+    CameraD cam; ItemGeometry ig; float tmin;
+    uint32_t tiles; uint32_t* cls; uint32_t* order;
+};
+
+// Eight probe rays per tile (corners and edge midpoints of the tile's pixel rectangle, through the lens
+// centre), one lane each; class = the largest over the probes of {0 miss, 1 lambertian, 2 metal/dielectric}.
+__global__ void __launch_bounds__(256) k_tile_class(const TileArgs a)
+{
+    const uint32_t t = blockIdx.x * 256u + threadIdx.x;
+    const uint32_t tile = t >> 3, sub = t & 7u;
+    uint32_t cls = 0;
+    if (tile < a.tiles) {
+        const int ty = (int)(tile / (uint32_t)a.ig.tiles_x), tx = (int)(tile - (uint32_t)ty * (uint32_t)a.ig.tiles_x);
+        const int r0 = ty * 8, r1 = (r0 + 7 < a.ig.owned_rows) ? r0 + 7 : a.ig.owned_rows - 1;
+        const int y0 = owned_row_to_y2(a.ig.band_rows, a.ig.band_first, a.ig.band_step, r0);
+        const int y1 = owned_row_to_y2(a.ig.band_rows, a.ig.band_first, a.ig.band_step, r1);
+        const float x_lo = (float)(tx * 8), x_hi = (float)((tx * 8 + 8 < a.ig.width) ? tx * 8 + 8 : a.ig.width);
+        const float v_hi = (float)(a.ig.height - y0), v_lo = (float)(a.ig.height - 1 - y1);
+        // probes 0..7 on a 3 x 3 grid without its centre
+        const int g = (int)(sub < 4u ? sub : sub + 1u);
+        const int gx = g % 3, gy = g / 3;
+        const float px = gx == 0 ? x_lo : gx == 1 ? 0.5f * (x_lo + x_hi) : x_hi;
+        const float py = gy == 0 ? v_lo : gy == 1 ? 0.5f * (v_lo + v_hi) : v_hi;
+        const RayD ray = get_ray(a.cam, px / (float)a.ig.width, py / (float)a.ig.height, 0.0f, 0.0f);
+        float closest = FLT_MAX; int hit = -1;
+        const float qa = dot(ray.d, ray.d);
+        for (int k = 0; k < a.n; ++k) {
+            const float4 gk = a.geom[k];
+            const V3 oc = ray.o - mk(gk.x, gk.y, gk.z);
+            const float b = dot(oc, ray.d);
+            const float desc = b * b - qa * (dot(oc, oc) - gk.w);
+            if (desc > 0.0f) {
+                const float sq = sqrtf(desc);
+                float temp = (-b - sq) / qa;
+                if (!(temp < closest && temp > a.tmin)) temp = (-b + sq) / qa;
+                if (temp < closest && temp > a.tmin) { closest = temp; hit = k; }
+            }
+        }
+        if (hit >= 0) cls = a.aux[hit].type == RT_LAMBERTIAN ? 1u : 2u;
+    }
+    for (int off = 1; off < 8; off <<= 1) { const uint32_t o = (uint32_t)__shfl_xor((int)cls, off); cls = o > cls ? o : cls; }
+    if (tile < a.tiles && sub == 0u) a.cls[tile] = cls;
+}
+
+// Stable counting sort of the tiles by class, highest class first (one block).
+__global__ void __launch_bounds__(1024) k_tile_order(const TileArgs a)
+{
+    __shared__ uint32_t s_count[3];
+    __shared__ uint32_t s_wave[16][3];
+    __shared__ uint32_t s_run[3];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    if (threadIdx.x < 3) s_count[threadIdx.x] = 0;
+    __syncthreads();
+    uint32_t mine[3] = { 0, 0, 0 };
+    for (uint32_t i = threadIdx.x; i < a.tiles; i += 1024u) mine[a.cls[i]] += 1u;
+    for (int c = 0; c < 3; ++c) if (mine[c]) atomicAdd(&s_count[c], mine[c]);
+    __syncthreads();
+    if (threadIdx.x == 0) { s_run[2] = 0; s_run[1] = s_count[2]; s_run[0] = s_count[2] + s_count[1]; }
+    __syncthreads();
+    for (uint32_t base = 0; base < a.tiles; base += 1024u) {
+        const uint32_t i = base + threadIdx.x;
+        const uint32_t c = i < a.tiles ? a.cls[i] : 3u;
+        uint32_t rank = 0;
+        for (uint32_t k = 0; k < 3; ++k) {
+            const unsigned long long m = __ballot(c == k);
+            if (c == k) rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
+            if (lane == 0) s_wave[wave][k] = (uint32_t)__popcll(m);
+        }
+        __syncthreads();
+        if (c < 3u) {
+            uint32_t before = s_run[c];
+            for (int w = 0; w < wave; ++w) before += s_wave[w][c];
+            a.order[before + rank] = i;
+        }
+        __syncthreads();
+        if (threadIdx.x < 3) { uint32_t tot = 0; for (int w = 0; w < 16; ++w) tot += s_wave[w][threadIdx.x]; s_run[threadIdx.x] += tot; }
+        __syncthreads();
+    }
+}
+
+template <bool kLds, bool kPlane, bool kRecLds = false, bool kBvh = false>
+__global__ void __launch_bounds__(kTraceBlock) k_trace(const TraceArgs a)
+{
+    extern __shared__ float4 smem[];
+    // LDS: [geom n][mat n][aux n (8 B)] when kLds.
+    float4* s_geom = smem;
+    float4* s_mat = smem + (kLds ? a.n : 0);
+    Aux* s_aux = reinterpret_cast<Aux*>(smem + (kLds ? 2 * a.n : 0));
+    if (kLds) {
+        for (int i = threadIdx.x; i < a.n; i += kTraceBlock) { s_geom[i] = a.geom[i]; s_mat[i] = a.mat[i]; s_aux[i] = a.aux[i]; }
+    }
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    // Per-lane filter masks of one super-chunk: word w of lane l at mask_words[w * 64] (lanes contiguous).
+    char* lds_after_scene = reinterpret_cast<char*>(smem) + (kLds ? (size_t)a.n * kLdsBytesPerSphere : 0);
+    // (In RT_MODE_BVH the same area holds each lane's stack of pending nodes instead.)
+    constexpr int kWordsPerLane = kBvh ? kBvhStack : kSuperChunkWords;
+    uint32_t* mask_words = reinterpret_cast<uint32_t*>(lds_after_scene) + (size_t)wave * kWordsPerLane * 64 + lane;
+    // Measurement variant (kRecLds): plane-filter records mirrored in LDS and read by broadcast ds_read_b128
+    // instead of by scalar load.
+    float4* s_prec = reinterpret_cast<float4*>(lds_after_scene + (size_t)(kTraceBlock / 64) * kWordsPerLane * 64 * sizeof(uint32_t));
+    if (kRecLds) { for (int i = threadIdx.x; i < a.n_pad; i += kTraceBlock) s_prec[i] = a.prec[i]; }
+    __syncthreads();
+    // The recursion's attenuation chain is replayed innermost-first when a path reaches the sky, so
+    // each lane keeps the indices of the spheres it bounced off.  One 2-byte store per bounce and a
+    // short read-back per finished path: kept in HBM so that LDS does not limit occupancy (packing the
+    // first levels into registers was measured 1.5 % slower: the loads are hidden by the other waves).
+    uint16_t* stack = a.stacks + (size_t)blockIdx.x * kTraceBlock + threadIdx.x;
+    const size_t sstride = a.stack_stride;
+
+    KeyedUniforms U; U.k0 = a.k0; U.k1 = a.k1; U.slot(0, 0, 0); U.cur = U4{ 0, 0, 0, 0 };
+    RayD ray; ray.o = mk(0, 0, 0); ray.d = mk(0, 0, 1);
+    int depth = 0; uint32_t item = 0, pix = 0, smp = 0;
+    bool active = false;
+    uint32_t rays = 0, misses = 0;
+    uint32_t pool_next = 0, pool_end = 0, pool_base = 0;      // wave-uniform
+    float* staged = a.staging + ((size_t)blockIdx.x * (kTraceBlock / 64) + wave) * (kStagingRows * kChunkItems);
+    bool exhausted = false;                    // wave-uniform
+    bool first_chunk = true;                   // wave-uniform
+    const float fnx = (float)a.width, fny = (float)a.height;
+    SecTimer T; T.start();
+    ItemGeometry ig; ig.width = a.width; ig.height = a.height; ig.band_rows = a.band_rows; ig.band_first = a.band_first; ig.band_step = a.band_step;
+    ig.owned_rows = a.owned_rows; ig.tiles_x = a.tiles_x; ig.Q = a.Q; ig.s_begin = a.s_begin; ig.s_count = a.s_count; ig.tile_order = a.tile_order;
+    SweepScene sw; sw.frec = a.frec; sw.prec = a.prec; sw.plane_s0 = a.plane_s0; sw.plane_rmin = a.plane_rmin; sw.geom = a.geom; sw.n = a.n; sw.n_pad = a.n_pad;
+
+#ifdef RT_WAVE_TIMELINE
+    const unsigned long long t_enter = __builtin_amdgcn_s_memrealtime(); unsigned long long t_dry = 0, trips_dry = 0, sparse_trips = 0, sparse_ticks = 0, t_trip = 0, t_first_sweep = 0, t_first_done = 0; bool was_sparse = false;
+#endif
+    for (;;) {
+#ifdef RT_WAVE_TIMELINE
+        if (exhausted) { if (t_dry == 0) t_dry = __builtin_amdgcn_s_memrealtime(); ++trips_dry; }
+        { const unsigned long long now = __builtin_amdgcn_s_memrealtime(); if (was_sparse) { ++sparse_trips; sparse_ticks += now - t_trip; } t_trip = now; was_sparse = false; }
+#endif
+        // ---------------------------------------------------------------- hand out new items
+        unsigned long long need = __ballot(!active);
+        while (need != 0ull && !(exhausted && pool_next == pool_end)) {
+            if (pool_next == pool_end) {
+                unsigned int g = 0;
+                // Chunks shrink towards the end of the work (down to a floor that keeps the hand-out cheap next to
+                // the sweep) so that the waves run out of items at nearly the same time: with full-size chunks to the
+                // last, a wave can start a whole chunk
+                // (some twenty trips) just before the counter runs dry while its neighbours go idle.  What is left
+                // is estimated from this wave's previous reservation and one chunk per resident wave since.
+                uint32_t take = (uint32_t)a.chunk_items;
+                {
+                    const uint32_t seen = pool_end + a.resident_waves * take;
+                    const uint32_t left = a.total_items > seen ? a.total_items - seen : 0u;
+                    const uint32_t fair = (left / (a.resident_waves * 2u)) & ~63u;
+                    if (fair < take) take = fair < a.min_chunk_items ? a.min_chunk_items : fair;
+                }
+                if (first_chunk) {
+                    // every wave's first chunk is fixed by its position in the grid (the host starts the counter
+                    // behind them): thousands of waves asking one counter word at the same instant would queue
+                    // for some 70 us at the start of every launch
+                    first_chunk = false;
+                    take = (uint32_t)a.chunk_items;
+                    g = (blockIdx.x * (uint32_t)(kTraceBlock / 64) + (uint32_t)wave) * take;
+                } else {
+                    if (lane == 0) g = atomicAdd(a.work_counter, take);
+                    g = __builtin_amdgcn_readfirstlane(g);
+                }
+                if (g >= a.total_items) { exhausted = true; break; }
+                pool_next = g; pool_base = g;
+                pool_end = (a.total_items - g < take) ? a.total_items : g + take;
+                // Generate the camera rays of the whole chunk now, all lanes busy, into this wave's staging
+                // rows in HBM; handing an item to a lane later is then eight loads.  (Generating on demand
+                // ran this code on every trip of the main loop for the third of the lanes that had finished.)
+                for (uint32_t it = g + (uint32_t)lane; it < pool_end; it += 64u) {
+                    uint32_t gp = 0xffffffffu, gs = 0u, gstore = 0u; int i = 0, j = 0;
+                    RayD gr; gr.o = mk(0, 0, 0); gr.d = mk(0, 0, 0);
+                    if (decode_item(ig, it, gp, gs, i, j, gstore)) gr = camera_ray(a.cam, gp, gs, i, j, fnx, fny, a.k0, a.k1);
+                    else gp = 0xffffffffu;
+                    const uint32_t slot = it - g;
+                    staged[0 * kChunkItems + slot] = gr.o.x; staged[1 * kChunkItems + slot] = gr.o.y; staged[2 * kChunkItems + slot] = gr.o.z;
+                    staged[3 * kChunkItems + slot] = gr.d.x; staged[4 * kChunkItems + slot] = gr.d.y; staged[5 * kChunkItems + slot] = gr.d.z;
+                    staged[6 * kChunkItems + slot] = __uint_as_float(gp); staged[7 * kChunkItems + slot] = __uint_as_float(gs);
+                    staged[8 * kChunkItems + slot] = __uint_as_float(gstore);
+                }
+                // the rows are read back by other lanes of this wave: drain the stores first
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            }
+            const uint32_t avail = pool_end - pool_next;
+            const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(need >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)need, 0u));
+            const uint32_t want = (uint32_t)__popcll(need);
+            if (!active && rank < avail) {
+                const uint32_t slot = pool_next + rank - pool_base;
+                // device-scope loads: the staging rows are rewritten for every chunk, so a stale L1 line
+                // from the previous chunk must not be served
+                const uint32_t gp = __float_as_uint(staged_load(staged + 6 * kChunkItems + slot));
+                if (gp != 0xffffffffu) {            // 0xffffffff marks a padding pixel of an edge tile
+                    pix = gp;
+                    smp = __float_as_uint(staged_load(staged + 7 * kChunkItems + slot));
+                    item = __float_as_uint(staged_load(staged + 8 * kChunkItems + slot));      // where the sample is stored
+                    ray.o = mk(staged_load(staged + 0 * kChunkItems + slot), staged_load(staged + 1 * kChunkItems + slot), staged_load(staged + 2 * kChunkItems + slot));
+                    ray.d = mk(staged_load(staged + 3 * kChunkItems + slot), staged_load(staged + 4 * kChunkItems + slot), staged_load(staged + 5 * kChunkItems + slot));
+                    depth = 0;
+                    active = true;
+                }
+            }
+            pool_next += (want < avail ? want : avail);
+            need = __ballot(!active);
+            // padding pixels leave their lane idle; they are re-served next trip, which is harmless
+            if (want <= avail) break;
+        }
+        T.mark(0);
+        if (!__any(active)) {
+            if (exhausted && pool_next == pool_end) break;
+            continue;
+        }
+
+        // A path of L bounces needs L trips of its wave, and with six waves taking turns on a SIMD a trip lasts
+        // six times its issue time: a 50-bounce path started late keeps the whole launch waiting.  Waves that
+        // hold a deep path are therefore given issue priority over their neighbours (same total work, the long
+        // chains just finish sooner).
+        {
+            const int deepest = __any(active && depth >= RT_PRIO_3) ? 3 : __any(active && depth >= RT_PRIO_2) ? 2 : __any(active && depth >= RT_PRIO_1) ? 1 : 0;
+            if (deepest == 3) __builtin_amdgcn_s_setprio(3);
+            else if (deepest == 2) __builtin_amdgcn_s_setprio(2);
+            else if (deepest == 1) __builtin_amdgcn_s_setprio(1);
+            else __builtin_amdgcn_s_setprio(0);
+        }
+        float closest = FLT_MAX; int hit = -1;
+        const unsigned long long live = __ballot(active);
+#ifdef RT_WAVE_TIMELINE
+        was_sparse = __popcll(live) <= kFewPaths && live != 0ull;
+        if (t_first_sweep == 0) t_first_sweep = __builtin_amdgcn_s_memrealtime();
+        else if (t_first_done == 0) t_first_done = __builtin_amdgcn_s_memrealtime();
+#endif
+        if (kBvh) { if (active) closest_hit_bvh<kLds>(ray, a.tmin, a.bvh, s_geom, mask_words, closest, hit); }
+        else if (__popcll(live) <= kFewPaths) closest_hit_few<kLds>(ray, a.tmin, sw, s_geom, live, lane, closest, hit);
+        else if (active) closest_hit<kLds, kPlane, kRecLds>(ray, a.tmin, sw, s_geom, s_prec, mask_words, closest, hit, T);
+        if (active) {
+            T.mark(4);
+            ++rays; misses += hit < 0 ? 1u : 0u;
+            // ------------------------------------------------------------ shade (main.cpp:13-39)
+            V3 sample;
+            const bool done = shade_step<kLds>(ray, depth, closest, hit, pix, smp, a.max_depth, U, s_geom, s_mat, s_aux, a.geom, a.mat, a.aux, stack, sstride, sample, T);
+            if (done) {
+                float* o = a.samples + (size_t)item * 3;
+                o[0] = sample.x; o[1] = sample.y; o[2] = sample.z;
+                active = false;
+            }
+            T.mark(7);
+        }
+    }
+    T.flush(lane);
+#ifdef RT_WAVE_TIMELINE
+    {
+        const uint32_t w = blockIdx.x * (kTraceBlock / 64) + wave;
+        if (lane == 0 && w < 8192u) { g_wave_times[0][w] = t_enter; const unsigned long long t_exit = __builtin_amdgcn_s_memrealtime(); g_wave_times[1][w] = t_dry ? t_dry : t_exit; g_wave_times[2][w] = t_exit; g_wave_times[3][w] = trips_dry; g_wave_times[4][w] = sparse_trips; g_wave_times[5][w] = sparse_ticks; g_wave_times[6][w] = t_first_sweep; g_wave_times[7][w] = t_first_done; }
+    }
+#endif
+    // one atomic per wave
+    for (int off = 32; off > 0; off >>= 1) { rays += __shfl_down(rays, off); misses += __shfl_down(misses, off); }
+    if (lane == 0 && rays) { atomicAdd(a.ray_counter, (unsigned long long)rays); atomicAdd(a.ray_counter + 1, (unsigned long long)misses); }
+}
+
+// Ordered per-pixel sum of a sample batch: col += sample for s ascending, exactly the
+// accumulation order of main.cpp:124-134; the last batch applies `col /= ns` and quantises.
+struct ResolveArgs {
+    const float* samples; float* accum;     // accum: [Q][3] running sums
+    uint32_t Q; int tiles_x; int s_count; int first, last;
+    int width, owned_rows, spp;
+    float* rgb_mean; int32_t* irgb;
+};
+__global__ void __launch_bounds__(256) k_resolve(const ResolveArgs a)
+{
+    const uint32_t q = blockIdx.x * 256u + threadIdx.x;
+    if (q >= a.Q) return;
+    V3 col = a.first ? mk(0.0f, 0.0f, 0.0f) : mk(a.accum[3 * (size_t)q], a.accum[3 * (size_t)q + 1], a.accum[3 * (size_t)q + 2]);
+    const uint32_t tile = q >> 6, l = q & 63u;
+    const int ty = (int)(tile / (uint32_t)a.tiles_x), tx = (int)(tile - (uint32_t)ty * (uint32_t)a.tiles_x);
+    const int i = tx * 8 + (int)(l & 7u), r = ty * 8 + (int)(l >> 3);
+    if (i >= a.width || r >= a.owned_rows) return;
+    const float* sp = a.samples + 3 * ((size_t)tile * a.s_count * 64 + l);       // item = (tile * s_count + s) * 64 + l
+    for (int s = 0; s < a.s_count; ++s, sp += 3 * 64) col = col + mk(sp[0], sp[1], sp[2]);
+    if (!a.last) { a.accum[3 * (size_t)q] = col.x; a.accum[3 * (size_t)q + 1] = col.y; a.accum[3 * (size_t)q + 2] = col.z; return; }
+    const float inv = 1.0f / (float)a.spp;          // Vec3::operator/=(float), vec3.cpp:109-118
+    const float mr = col.x * inv, mg = col.y * inv, mb = col.z * inv;
+    const size_t o = ((size_t)r * a.width + i) * 3;
+    if (a.rgb_mean) { a.rgb_mean[o] = mr; a.rgb_mean[o + 1] = mg; a.rgb_mean[o + 2] = mb; }
+    if (a.irgb) { a.irgb[o] = quantise(mr); a.irgb[o + 1] = quantise(mg); a.irgb[o + 2] = quantise(mb); }
+}
+#ifdef RT_SECTION_TIMERS
+extern "C" int rt_debug_section_ticks(unsigned long long* out8, int reset)
+{
+    if (out8 && hipMemcpyFromSymbol(out8, HIP_SYMBOL(g_section_ticks), 8 * sizeof(unsigned long long)) != hipSuccess) return -3;
+    if (reset) { unsigned long long z[8] = { 0 }; if (hipMemcpyToSymbol(HIP_SYMBOL(g_section_ticks), z, sizeof z) != hipSuccess) return -3; }
+    return 0;
+}
+#endif
+#ifdef RT_WAVE_TIMELINE
+extern "C" int rt_debug_wave_times(unsigned long long* out_6x8192)   /* 8 rows of 8192 */
+{
+    return hipMemcpyFromSymbol(out_6x8192, HIP_SYMBOL(g_wave_times), 8 * 8192 * sizeof(unsigned long long)) == hipSuccess ? 0 : -3;
+}
+#endif
+
+namespace {
+using TraceKernel = void (*)(const TraceArgs);
+TraceKernel trace_kernel(const TracePlan& t)
+{
+    if (t.bvh) return t.lds ? k_trace<true, true, false, true> : k_trace<false, true, false, true>;
+    if (t.reclds) return k_trace<true, true, true>;
+    if (t.lds) return t.plane ? k_trace<true, true> : k_trace<true, false>;
+    return t.plane ? k_trace<false, true> : k_trace<false, false>;
+}
+}  // namespace
+
+// Settles what every batch of the call shares: which instantiation of k_trace runs and how many of its blocks fit a CU,
+// the per-lane hit stacks and per-wave staging rows for that many resident waves, and the work order of the tiles.
+int trace_prepare(rt_context* ctx, const RenderFrame& f, TracePlan* plan)
+{
+    const rt_params* p = f.p;
+    hipStream_t st = f.st;
+    TracePlan& t = *plan;
+    t.lds = ctx->n <= kMaxLdsSpheres;
+    t.plane = ctx->plane_filter;
+    t.bvh = p->mode == RT_MODE_BVH;
+    t.reclds = !t.bvh && ctx->records_in_lds && t.lds && t.plane && ctx->n_pad <= 2048;
+    t.shmem = (t.lds ? (size_t)ctx->n * kLdsBytesPerSphere : 0) + (size_t)(kTraceBlock / 64) * (t.bvh ? kBvhStack : kSuperChunkWords) * 64 * sizeof(uint32_t) +
+              (t.reclds ? (size_t)ctx->n_pad * sizeof(float4) : 0);
+    int& bpc = ctx->trace_blocks_per_cu[t.bvh ? (t.lds ? 6 : 5) : t.reclds ? 4 : (t.lds ? 1 : 0) + (t.plane ? 2 : 0)];
+    if (bpc == 0) {
+        int nb = 0;
+        hipError_t e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, trace_kernel(t), kTraceBlock, t.shmem);
+        if (e != hipSuccess || nb <= 0) nb = 1;
+        bpc = nb;
+    }
+    t.blocks_per_cu = bpc;
+    const size_t lanes = (size_t)ctx->num_cu * bpc * kTraceBlock;
+    if (ctx->stacks_lanes < lanes) {
+        HIP_TRY(ctx, hipStreamSynchronize(st));
+        (void)hipFree(ctx->d_stacks); ctx->d_stacks = nullptr; ctx->stacks_lanes = 0;
+        (void)hipFree(ctx->d_staging); ctx->d_staging = nullptr;
+        HIP_TRY(ctx, hipMalloc(&ctx->d_stacks, lanes * RT_MAX_DEPTH * sizeof(uint16_t)));
+        HIP_TRY(ctx, hipMalloc(&ctx->d_staging, (lanes / 64) * kStagingRows * kChunkItems * sizeof(float)));
+        ctx->stacks_lanes = lanes;
+    }
+    t.ordered = ctx->tile_ordering;
+    if (!t.ordered) return RT_OK;
+    const uint32_t n_tiles = (uint32_t)(f.Q / 64);
+    if (ctx->tile_cap < n_tiles) {
+        HIP_TRY(ctx, hipStreamSynchronize(st));
+        (void)hipFree(ctx->d_tile_cls); (void)hipFree(ctx->d_tile_order); ctx->d_tile_cls = ctx->d_tile_order = nullptr; ctx->tile_cap = 0; ctx->tile_key_valid = false;
+        HIP_TRY(ctx, hipMalloc(&ctx->d_tile_cls, (size_t)n_tiles * sizeof(uint32_t)));
+        HIP_TRY(ctx, hipMalloc(&ctx->d_tile_order, (size_t)n_tiles * sizeof(uint32_t)));
+        ctx->tile_cap = n_tiles;
+    }
+    const rt_context::TileKey key{ ctx->scene_version, ctx->camera_version, p->width, p->height, p->band_rows, p->band_first, p->band_step, p->tmin };
+    if (ctx->tile_key_valid && memcmp(&key, &ctx->tile_key, sizeof key) == 0) return RT_OK;
+    TileArgs ta{};
+    ta.geom = ctx->d_geom; ta.aux = ctx->d_aux; ta.n = ctx->n; ta.cam = ctx->cam; ta.tmin = p->tmin;
+    ta.ig.width = p->width; ta.ig.height = p->height; ta.ig.band_rows = p->band_rows; ta.ig.band_first = p->band_first; ta.ig.band_step = p->band_step;
+    ta.ig.owned_rows = f.owned; ta.ig.tiles_x = f.tiles_x; ta.ig.Q = (uint32_t)f.Q; ta.ig.s_begin = 0; ta.ig.s_count = 1; ta.ig.tile_order = nullptr;
+    ta.tiles = n_tiles; ta.cls = ctx->d_tile_cls; ta.order = ctx->d_tile_order;
+    hipLaunchKernelGGL(k_tile_class, dim3((n_tiles * 8u + 255u) / 256u), dim3(256), 0, st, ta);
+    hipLaunchKernelGGL(k_tile_order, dim3(1), dim3(1024), 0, st, ta);
+    HIP_TRY(ctx, hipGetLastError());
+    ctx->tile_key = key; ctx->tile_key_valid = true;
+    return RT_OK;
+}
+
+int trace_batch(rt_context* ctx, const RenderFrame& f, const TracePlan& t, const SampleBatch& b)
+{
+    const rt_params* p = f.p;
+    TraceArgs a;
+    a.prec = ctx->d_prec; a.plane_s0 = ctx->plane_s0; a.plane_rmin = ctx->plane_rmin; a.frec = ctx->d_frec; a.geom = ctx->d_geom; a.mat = ctx->d_mat; a.aux = ctx->d_aux; a.n = ctx->n; a.n_pad = ctx->n_pad; a.cam = ctx->cam;
+    a.width = p->width; a.height = p->height; a.max_depth = p->max_depth; a.tmin = p->tmin;
+    a.k0 = (uint32_t)p->seed; a.k1 = (uint32_t)(p->seed >> 32);
+    a.band_rows = p->band_rows; a.band_first = p->band_first; a.band_step = p->band_step; a.owned_rows = f.owned;
+    a.tiles_x = f.tiles_x; a.Q = (uint32_t)f.Q; a.s_begin = b.s0; a.s_count = b.sc; a.total_items = (uint32_t)(f.Q * b.sc);
+    a.samples = ctx->d_samples; a.ray_counter = ctx->d_rays; a.work_counter = ctx->d_work;
+    a.stacks = ctx->d_stacks; a.stack_stride = (uint32_t)ctx->stacks_lanes; a.staging = ctx->d_staging;
+    a.tile_order = t.ordered ? ctx->d_tile_order : nullptr;
+    a.bvh.nodes = ctx->d_bvh_nodes; a.bvh.leaf_index = ctx->d_bvh_leaf; a.bvh.big = ctx->d_bvh_big; a.bvh.n_big = ctx->bvh_n_big; a.bvh.geom = ctx->d_geom;
+    // small jobs take smaller chunks so that every resident wave gets several (tail balance)
+    const uint64_t resident_waves = (uint64_t)ctx->num_cu * t.blocks_per_cu * (kTraceBlock / 64);
+    uint64_t chunk = (uint64_t)a.total_items / (resident_waves * 16) / 64 * 64;
+    const uint64_t floor_items = (32768ull / (uint64_t)ctx->n_pad + 63) / 64 * 64;     // tiny scenes: keep per-chunk work above the hand-out overhead
+    if (chunk < floor_items) chunk = floor_items;
+    a.chunk_items = (int)(chunk < 64 ? 64 : (chunk > (uint64_t)kChunkItems ? (uint64_t)kChunkItems : chunk));
+    a.resident_waves = (uint32_t)resident_waves;
+    { const uint64_t m = floor_items < 64 ? 64 : floor_items; a.min_chunk_items = (uint32_t)(m < (uint64_t)a.chunk_items ? m : (uint64_t)a.chunk_items); }
+    const uint64_t want_blocks = ((uint64_t)a.total_items + (uint64_t)a.chunk_items * (kTraceBlock / 64) - 1) / ((uint64_t)a.chunk_items * (kTraceBlock / 64));
+    const uint64_t cap_blocks = (uint64_t)ctx->num_cu * t.blocks_per_cu;
+    const dim3 grid((unsigned)(want_blocks < cap_blocks ? want_blocks : cap_blocks)), block(kTraceBlock);
+    // the first chunk of every launched wave is implied by its index; the counter hands out what follows
+    HIP_TRY(ctx, hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(ctx->d_work), (int)(grid.x * (unsigned)(kTraceBlock / 64) * (unsigned)a.chunk_items), 1, f.st));
+    hipLaunchKernelGGL(trace_kernel(t), grid, block, t.shmem, f.st, a);
+    HIP_TRY(ctx, hipGetLastError());
+    return RT_OK;
+}
+
+int resolve_batch(rt_context* ctx, const RenderFrame& f, const SampleBatch& b)
+{
+    ResolveArgs r;
+    r.samples = ctx->d_samples; r.accum = ctx->d_accum; r.Q = (uint32_t)f.Q; r.tiles_x = f.tiles_x; r.s_count = b.sc;
+    r.first = (b.index == 0); r.last = (b.index == f.batches - 1); r.width = f.p->width; r.owned_rows = f.owned; r.spp = f.p->spp;
+    r.rgb_mean = f.d_rgb_mean; r.irgb = f.d_irgb;
+    hipLaunchKernelGGL(k_resolve, dim3((unsigned)((f.Q + 255) / 256)), dim3(256), 0, f.st, r);
+    HIP_TRY(ctx, hipGetLastError());
+    return RT_OK;
+}
