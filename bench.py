@@ -26,6 +26,9 @@ import raytracing_amd as R                                   # noqa: E402
 from raytracing_amd import dist as rdist                     # noqa: E402
 
 PEAK_FP32_VALU_TFLOPS = 157.3      # 256 CU x 4 SIMD x 32 lanes x 2 flop (FMA) x 2.4 GHz
+# plain v_fma_f32 chains held for 0.1-1 s on this part (tools/ubench_sustain.hip); the plain FMA runs at the full rate, so the
+# 78.6 TFLOP/s "non-packed" figure quoted for older parts is not a ceiling here
+SUSTAINED_FP32_FMA_TFLOPS = 148.0
 FLOP_PER_TEST = 18                 # oc (3) + oc.d (5) + oc.oc (5) + -r^2 (1) + b^2 (1) + a*c (1) + - (1) + compare (1)
 FLOP_PER_RAY_EXTRA = 150           # hit resolve + scatter, per closest-hit query
 # HBM bytes per ray of the render kernels from rocprofv3 FETCH_SIZE (x2, the gfx950 correction for coalesced reads) + WRITE_SIZE
@@ -246,6 +249,7 @@ def main():
             "kernel_ms_mean": kms_mean, "kernel_ms_max": kms_max,
             "roofline": {"bound": "valu", "achieved": achieved, "peak": PEAK_FP32_VALU_TFLOPS, "unit": "TFLOP/s",
                          "frac": achieved / PEAK_FP32_VALU_TFLOPS,
+                         "peak_sustained_measured": SUSTAINED_FP32_FMA_TFLOPS, "frac_of_sustained": achieved / SUSTAINED_FP32_FMA_TFLOPS,
                          "traffic": (HBM_BYTES_PER_RAY_PMC * my_rays) if args.mode == "megakernel" else None, "traffic_unit": "bytes per step of this rank (PMC-derived constant per ray)",
                          "kernel": {"megakernel": "k_trace", "wavefront": "k_wf_intersect + k_wf_shade", "pixel": "k_render_mega", "bvh": "k_trace (hierarchy walk)"}[args.mode], "flop_per_ray": flop_per_ray,
                          "note": "FP32 vector-ALU bound (HBM traffic and MFMA are not on this path); algorithmic flops = rays x (18 x spheres + 150)"},
