@@ -97,8 +97,20 @@ struct SweepScene {
     int n, n_pad;
 };
 
-template <bool kLds, bool kPlane, bool kRecLds>
-__device__ __forceinline__ void closest_hit(const RayD& ray, float tmin, const SweepScene& sw, const float4* s_geom, const float4* s_prec,
+// LDS mirror of the records the exact passes read.  Packed form (k_trace): geom[k] = (centre, constant of the discriminant
+// filter) and r*r is formed from aux[k].radius -- the same single float product the host stores in the HBM record -- so a sphere
+// costs no more LDS than before the filter constant moved in.  Plain form (wavefront intersect): geom[k] = (centre, r*r) as in
+// HBM and the constants in an array of their own.
+struct ExactLds { const float4* geom; const Aux* aux; const float* disck; };
+template <bool kFromRadius>
+__device__ __forceinline__ float exact_r2(const float4& g, const ExactLds& lds, int k)
+{
+    if (kFromRadius) { const float r = lds.aux[k].radius; return r * r; }
+    return g.w;
+}
+
+template <bool kLds, bool kPlane, bool kRecLds, bool kPacked>
+__device__ __forceinline__ void closest_hit(const RayD& ray, float tmin, const SweepScene& sw, const ExactLds& lds, const float4* s_prec,
                                             uint32_t* mask_words, float& closest, int& hit, SecTimer& T)
 {
     // Per ray: unit direction (approximate is enough for a conservative test), -(o.d^), 2o,
@@ -190,11 +202,14 @@ __device__ __forceinline__ void closest_hit(const RayD& ray, float tmin, const S
         }
         nz <<= (32 - words);
         T.mark(1);
-        // Pass A: exact discriminant of every survivor of the filter (sphere.cpp:17-25); the bits of
-        // those with desc <= 0 are cleared in place.  Pass B: roots, range test and running minimum
-        // (sphere.cpp:27-50, hittablelist.cpp:21-29) for what is left, in ascending index order.
-        // Splitting keeps the square root and the two divisions out of the long first loop, where
-        // some lane of the wave would otherwise need them on every trip.
+        // Pass A: every survivor of the plane filter goes through the discriminant filter (the 8-FMA form
+        // above, on the same per-ray constants and the per-sphere constant k; it never rejects a sphere
+        // whose reference discriminant is positive), and the bits of the rejected ones are cleared in
+        // place.  Pass B: the reference's own discriminant, roots, range test and running minimum
+        // (sphere.cpp:17-50, hittablelist.cpp:21-29) for the two or so per ray that are left, in
+        // ascending index order.  Pass A is the long loop (a dozen trips per ray, the wave waits for its
+        // slowest lane), so it holds the cheap conservative test; the unfused arithmetic, the square
+        // root and the two divisions are paid only in pass B.
         // Every word flagged in nz is non-zero, and padding records never pass the filter, so each bit
         // visited names a real sphere (k < n).
         uint32_t nzb = 0u;
@@ -208,12 +223,12 @@ __device__ __forceinline__ void closest_hit(const RayD& ray, float tmin, const S
                 const uint32_t bit = 0x80000000u >> jj;
                 cand &= ~bit;
                 const int k = cbase + jj;
-                const float4 g = kLds ? s_geom[k] : sw.geom[k];
-                const V3 oc = ray.o - mk(g.x, g.y, g.z);
-                const float b = dot(oc, ray.d);
-                const float cc = dot(oc, oc) - g.w;
-                const float desc = b * b - qa * cc;
-                if (desc > 0.0f) keep |= bit;
+                const float4 g = kLds ? lds.geom[k] : sw.geom[k];
+                const float dk = !kLds ? sw.frec[k].w : kPacked ? g.w : lds.disck[k];
+                const float b = fmaf(g.x, hx, fmaf(g.y, hy, fmaf(g.z, hz, nod)));
+                const float ew = fmaf(g.x, p2x, fmaf(g.y, p2y, fmaf(g.z, p2z, noo)));
+                const float e = fmaf(b, b, ew);
+                if (!(e - dk < 0.0f)) keep |= bit;
                 if (cand == 0u) {
                     mask_words[w * 64] = keep;
                     nzb |= keep ? 0x80000000u >> w : 0u;
@@ -236,15 +251,15 @@ __device__ __forceinline__ void closest_hit(const RayD& ray, float tmin, const S
                 const int jj = __builtin_clz(cand);
                 cand &= ~(0x80000000u >> jj);
                 const int k = cbase + jj;
-                const float4 g = kLds ? s_geom[k] : sw.geom[k];
+                const float4 g = kLds ? lds.geom[k] : sw.geom[k];
                 const V3 oc = ray.o - mk(g.x, g.y, g.z);
                 const float b = dot(oc, ray.d);
-                const float cc = dot(oc, oc) - g.w;
+                const float cc = dot(oc, oc) - exact_r2<kLds && kPacked>(g, lds, k);
                 const float desc = b * b - qa * cc;
                 const float sq = sqrtf(desc);
                 float temp = (-b - sq) / qa;
                 if (!(temp < closest && temp > tmin)) temp = (-b + sq) / qa;
-                if (temp < closest && temp > tmin) { closest = temp; hit = k; }
+                if (desc > 0.0f && temp < closest && temp > tmin) { closest = temp; hit = k; }
                 if (cand == 0u) {
                     if (nzb == 0u) break;
                     w = __builtin_clz(nzb);
@@ -278,7 +293,7 @@ __device__ __forceinline__ void closest_hit(const RayD& ray, float tmin, const S
 #endif
 constexpr int kFewPaths = RT_FEW_PATHS;     // 2, 4 and 8 measure alike on the 1200x800 final scene at 10 spp, 16 and 24 are 4-6 % slower (tools/ab_few.sh)
 template <bool kLds>
-__device__ __forceinline__ void closest_hit_few(const RayD& ray, float tmin, const SweepScene& sw, const float4* s_geom,
+__device__ __forceinline__ void closest_hit_few(const RayD& ray, float tmin, const SweepScene& sw, const ExactLds& lds,
                                                 unsigned long long live, int lane, float& closest, int& hit)
 {
     while (live != 0ull) {
@@ -297,10 +312,10 @@ __device__ __forceinline__ void closest_hit_few(const RayD& ray, float tmin, con
             const int k = base + lane;
             float b = 0.0f, desc = -1.0f;
             if (k < sw.n) {
-                const float4 g = kLds ? s_geom[k] : sw.geom[k];
+                const float4 g = kLds ? lds.geom[k] : sw.geom[k];
                 const V3 oc = r.o - mk(g.x, g.y, g.z);
                 b = dot(oc, r.d);
-                const float cc = dot(oc, oc) - g.w;
+                const float cc = dot(oc, oc) - exact_r2<kLds>(g, lds, k);
                 desc = b * b - qa * cc;
             }
             if (__any(desc > 0.0f)) {
@@ -340,9 +355,9 @@ __device__ __forceinline__ void closest_hit_few(const RayD& ray, float tmin, con
 constexpr float kBvhSlack = 24.0f * 5.9604645e-08f;
 
 template <bool kLds>
-__device__ __forceinline__ void bvh_test_sphere(const RayD& ray, float qa, float tmin, const BvhScene& bv, const float4* s_geom, int k, float& closest, int& hit)
+__device__ __forceinline__ void bvh_test_sphere(const RayD& ray, float qa, float tmin, const BvhScene& bv, const ExactLds& lds, int k, float& closest, int& hit)
 {
-    const float4 g = kLds ? s_geom[k] : bv.geom[k];
+    const float4 g = kLds ? lds.geom[k] : bv.geom[k];       // plain form: (centre, r*r)
     const V3 oc = ray.o - mk(g.x, g.y, g.z);
     const float b = dot(oc, ray.d);
     const float cc = dot(oc, oc) - g.w;
@@ -380,16 +395,16 @@ __device__ __forceinline__ bool bvh_enter(const RayD& ray, float ix, float iy, f
 // children of a node together: leaves among them are tested at once, of two inner children the nearer is entered
 // and the other one's child pair is left pending (it is re-examined against the then-current closest hit when popped).
 template <bool kLds>
-__device__ __forceinline__ void closest_hit_bvh(const RayD& ray, float tmin, const BvhScene& bv, const float4* s_geom, uint32_t* pending, float& closest, int& hit)
+__device__ __forceinline__ void closest_hit_bvh(const RayD& ray, float tmin, const BvhScene& bv, const ExactLds& lds, uint32_t* pending, float& closest, int& hit)
 {
     const float qa = dot(ray.d, ray.d);
-    for (int j = 0; j < bv.n_big; ++j) bvh_test_sphere<kLds>(ray, qa, tmin, bv, s_geom, (int)bv.big[j], closest, hit);
+    for (int j = 0; j < bv.n_big; ++j) bvh_test_sphere<kLds>(ray, qa, tmin, bv, lds, (int)bv.big[j], closest, hit);
     const float ix = 1.0f / ray.d.x, iy = 1.0f / ray.d.y, iz = 1.0f / ray.d.z;
     const float omag = 1e-6f * (1.0f + fabsf(ray.o.x) + fabsf(ray.o.y) + fabsf(ray.o.z));     // the ray's share of the absolute margin
     const float t_low = tmin < 0.0f ? -FLT_MAX : 0.0f;
     auto test_leaf = [&](int link) {
         const int code = -(link + 1), first = code >> 3, count = (code & 7) + 1;
-        for (int q = 0; q < count; ++q) bvh_test_sphere<kLds>(ray, qa, tmin, bv, s_geom, (int)bv.leaf_index[first + q], closest, hit);
+        for (int q = 0; q < count; ++q) bvh_test_sphere<kLds>(ray, qa, tmin, bv, lds, (int)bv.leaf_index[first + q], closest, hit);
     };
     const int root_link = __float_as_int(bv.nodes[1].w);
     if (root_link < 0) {                    // at most one leaf in the whole tree

@@ -136,16 +136,18 @@ __global__ void __launch_bounds__(1024) k_tile_order(const TileArgs a)
 }
 
 template <bool kLds, bool kPlane, bool kRecLds = false, bool kBvh = false>
-__global__ void __launch_bounds__(kTraceBlock) k_trace(const TraceArgs a)
+__global__ void __launch_bounds__(kTraceBlock) __attribute__((amdgpu_waves_per_eu(kBvh && kLds ? 4 : 6, kBvh && kLds ? 4 : 6))) k_trace(const TraceArgs a)
 {
     extern __shared__ float4 smem[];
-    // LDS: [geom n][mat n][aux n (8 B)] when kLds.
+    // LDS: [geom n][mat n][aux n (8 B)] when kLds; geom in the packed form of ExactLds (centre, discriminant-filter constant)
+    // for the sweep, in the plain form (centre, r*r) for the hierarchy walk.
     float4* s_geom = smem;
     float4* s_mat = smem + (kLds ? a.n : 0);
     Aux* s_aux = reinterpret_cast<Aux*>(smem + (kLds ? 2 * a.n : 0));
     if (kLds) {
-        for (int i = threadIdx.x; i < a.n; i += kTraceBlock) { s_geom[i] = a.geom[i]; s_mat[i] = a.mat[i]; s_aux[i] = a.aux[i]; }
+        for (int i = threadIdx.x; i < a.n; i += kTraceBlock) { const float4 g = a.geom[i]; s_geom[i] = make_float4(g.x, g.y, g.z, kBvh ? g.w : a.frec[i].w); s_mat[i] = a.mat[i]; s_aux[i] = a.aux[i]; }
     }
+    const ExactLds exact_lds{ s_geom, s_aux, nullptr };
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     // Per-lane filter masks of one super-chunk: word w of lane l at mask_words[w * 64] (lanes contiguous).
     char* lds_after_scene = reinterpret_cast<char*>(smem) + (kLds ? (size_t)a.n * kLdsBytesPerSphere : 0);
@@ -283,9 +285,9 @@ __global__ void __launch_bounds__(kTraceBlock) k_trace(const TraceArgs a)
         if (t_first_sweep == 0) t_first_sweep = __builtin_amdgcn_s_memrealtime();
         else if (t_first_done == 0) t_first_done = __builtin_amdgcn_s_memrealtime();
 #endif
-        if (kBvh) { if (active) closest_hit_bvh<kLds>(ray, a.tmin, a.bvh, s_geom, mask_words, closest, hit); }
-        else if (__popcll(live) <= kFewPaths) closest_hit_few<kLds>(ray, a.tmin, sw, s_geom, live, lane, closest, hit);
-        else if (active) closest_hit<kLds, kPlane, kRecLds>(ray, a.tmin, sw, s_geom, s_prec, mask_words, closest, hit, T);
+        if (kBvh) { if (active) closest_hit_bvh<kLds>(ray, a.tmin, a.bvh, exact_lds, mask_words, closest, hit); }
+        else if (__popcll(live) <= kFewPaths) closest_hit_few<kLds>(ray, a.tmin, sw, exact_lds, live, lane, closest, hit);
+        else if (active) closest_hit<kLds, kPlane, kRecLds, true>(ray, a.tmin, sw, exact_lds, s_prec, mask_words, closest, hit, T);
         if (active) {
             T.mark(4);
             ++rays; misses += hit < 0 ? 1u : 0u;

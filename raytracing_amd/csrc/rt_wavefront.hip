@@ -47,9 +47,10 @@ __global__ void __launch_bounds__(kTraceBlock) k_wf_intersect(const WfArgs a)
 {
     extern __shared__ float4 smem[];
     float4* s_geom = smem;
-    if (kLds) { for (int i = threadIdx.x; i < a.sw.n; i += kTraceBlock) s_geom[i] = a.sw.geom[i]; }
+    float* s_disck = reinterpret_cast<float*>(smem + (kLds ? a.sw.n : 0));
+    if (kLds) { for (int i = threadIdx.x; i < a.sw.n; i += kTraceBlock) { s_geom[i] = a.sw.geom[i]; s_disck[i] = a.sw.frec[i].w; } }
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    uint32_t* mask_words = reinterpret_cast<uint32_t*>(reinterpret_cast<char*>(smem) + (kLds ? (size_t)a.sw.n * sizeof(float4) : 0)) + (size_t)wave * kSuperChunkWords * 64 + lane;
+    uint32_t* mask_words = reinterpret_cast<uint32_t*>(reinterpret_cast<char*>(smem) + (kLds ? ((size_t)a.sw.n * 20 + 15) / 16 * 16 : 0)) + (size_t)wave * kSuperChunkWords * 64 + lane;
     __syncthreads();
     const uint32_t n_in = *a.n_in;
     SecTimer T; T.start();
@@ -60,7 +61,7 @@ __global__ void __launch_bounds__(kTraceBlock) k_wf_intersect(const WfArgs a)
         ray.o = mk(a.ray[0 * (size_t)a.P + s], a.ray[1 * (size_t)a.P + s], a.ray[2 * (size_t)a.P + s]);
         ray.d = mk(a.ray[3 * (size_t)a.P + s], a.ray[4 * (size_t)a.P + s], a.ray[5 * (size_t)a.P + s]);
         float closest = FLT_MAX; int hit = -1;
-        if (a.pixsmp[s] != 0xffffffffu) closest_hit<kLds, kPlane, false>(ray, a.tmin, a.sw, s_geom, nullptr, mask_words, closest, hit, T);
+        if (a.pixsmp[s] != 0xffffffffu) closest_hit<kLds, kPlane, false, false>(ray, a.tmin, a.sw, ExactLds{ s_geom, nullptr, s_disck }, nullptr, mask_words, closest, hit, T);
         a.hit_t[s] = closest; a.hit_idx[s] = hit;
     }
 }
@@ -189,7 +190,7 @@ int wavefront_batch(rt_context* ctx, const RenderFrame& f, const SampleBatch& b)
     w.ray = ctx->wf_ray; w.pixsmp = ctx->wf_pixsmp; w.depth = ctx->wf_depth; w.hit_t = ctx->wf_hit_t; w.hit_idx = ctx->wf_hit_idx; w.stacks = ctx->wf_stacks;
     w.work_counter = ctx->d_work; w.ray_counter = ctx->d_rays; w.samples = ctx->d_samples;
     const bool wl = ctx->n <= 4096, wp = ctx->plane_filter;      // intersect keeps only the 16-byte exact records in LDS
-    const size_t wshmem = (wl ? (size_t)ctx->n * sizeof(float4) : 0) + (size_t)(kTraceBlock / 64) * kSuperChunkWords * 64 * sizeof(uint32_t);
+    const size_t wshmem = (wl ? ((size_t)ctx->n * 20 + 15) / 16 * 16 : 0) + (size_t)(kTraceBlock / 64) * kSuperChunkWords * 64 * sizeof(uint32_t);
     int& wbpc = ctx->wf_blocks_per_cu[(wl ? 1 : 0) + (wp ? 2 : 0)];
     auto ikern = wl ? (wp ? k_wf_intersect<true, true> : k_wf_intersect<true, false>) : (wp ? k_wf_intersect<false, true> : k_wf_intersect<false, false>);
     if (wbpc == 0) { int nb = 0; if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, ikern, kTraceBlock, wshmem) != hipSuccess || nb <= 0) nb = 1; wbpc = nb; }
