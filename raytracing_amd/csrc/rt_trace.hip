@@ -135,8 +135,16 @@ __global__ void __launch_bounds__(1024) k_tile_order(const TileArgs a)
     }
 }
 
+// Six waves per SIMD (three 512-thread blocks per CU) is what the LDS budget allows and what hides the latency of the exact
+// passes; the register allocation is held to it explicitly (80 VGPRs; the allocator's own choice drifts between 77 and 96
+// with small source changes).  The hierarchy walk with the scene in LDS fits two blocks per CU only, so it keeps more registers.
+#ifdef RT_SECTION_TIMERS
+#define RT_TRACE_WAVES(kBvh, kLds)      /* the timers' accumulators need the registers */
+#else
+#define RT_TRACE_WAVES(kBvh, kLds) __attribute__((amdgpu_waves_per_eu((kBvh) && (kLds) ? 4 : 6, (kBvh) && (kLds) ? 4 : 6)))
+#endif
 template <bool kLds, bool kPlane, bool kRecLds = false, bool kBvh = false>
-__global__ void __launch_bounds__(kTraceBlock) __attribute__((amdgpu_waves_per_eu(kBvh && kLds ? 4 : 6, kBvh && kLds ? 4 : 6))) k_trace(const TraceArgs a)
+__global__ void __launch_bounds__(kTraceBlock) RT_TRACE_WAVES(kBvh, kLds) k_trace(const TraceArgs a)
 {
     extern __shared__ float4 smem[];
     // LDS: [geom n][mat n][aux n (8 B)] when kLds; geom in the packed form of ExactLds (centre, discriminant-filter constant)
