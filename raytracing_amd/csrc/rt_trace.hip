@@ -11,13 +11,14 @@
 // lane's path ends it is handed the next item (ballot + prefix count), so every trip of the main
 // loop runs one closest-hit sweep with all lanes busy until the work runs out.
 //
-// The sweep (closest_hit) is split in two:
+// The sweep (closest_hit) is split in three:
 //   filter  (hot, branch-free, records as scalar operands): a conservative sign test per ray-sphere
 //            pair -- by default the distance of the centre to the vertical plane through the ray
 //            (3 FMAs), alternatively the whole discriminant expanded about the world origin (8 FMAs) --
 //            with a per-sphere and per-ray slack that dominates every rounding error of both this
 //            form and the reference's.  The sign bits of 32 spheres are shifted into one register.
-//   exact   (cold): the few spheres whose bit says "maybe" are evaluated with the reference's own
+//   pass A  (per lane, a dozen survivors per ray): the second of those two tests on the survivors of the first.
+//   pass B  (per lane, about two per ray): the spheres still standing are evaluated with the reference's own
 //            unfused arithmetic (sphere.cpp:15-52); the accepted root of each and the running minimum
 //            follow hittablelist.cpp:13-31, so the chosen sphere and t are bit-identical.
 // A wave left with only a few live paths (the end of a launch) switches to closest_hit_few.
