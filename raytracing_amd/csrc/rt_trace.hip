@@ -179,7 +179,7 @@ __global__ void __launch_bounds__(kTraceBlock) RT_TRACE_WAVES(kBvh, kLds) k_trac
     RayD ray; ray.o = mk(0, 0, 0); ray.d = mk(0, 0, 1);
     int depth = 0; uint32_t item = 0, pix = 0, smp = 0;
     bool active = false;
-    uint32_t rays = 0, misses = 0;
+    uint32_t rays = 0, misses = 0;             // wave-uniform: queries and sky misses of the whole wave
     uint32_t pool_next = 0, pool_end = 0, pool_base = 0;      // wave-uniform
     float* staged = a.staging + ((size_t)blockIdx.x * (kTraceBlock / 64) + wave) * (kStagingRows * kChunkItems);
     bool exhausted = false;                    // wave-uniform
@@ -297,9 +297,9 @@ __global__ void __launch_bounds__(kTraceBlock) RT_TRACE_WAVES(kBvh, kLds) k_trac
         if (kBvh) { if (active) closest_hit_bvh<kLds>(ray, a.tmin, a.bvh, exact_lds, mask_words, closest, hit); }
         else if (__popcll(live) <= kFewPaths) closest_hit_few<kLds>(ray, a.tmin, sw, exact_lds, live, lane, closest, hit);
         else if (active) closest_hit<kLds, kPlane, kRecLds, true>(ray, a.tmin, sw, exact_lds, s_prec, mask_words, closest, hit, T);
+        rays += (uint32_t)__popcll(live); misses += (uint32_t)__popcll(__ballot(active && hit < 0));
         if (active) {
             T.mark(4);
-            ++rays; misses += hit < 0 ? 1u : 0u;
             // ------------------------------------------------------------ shade (main.cpp:13-39)
             V3 sample;
             const bool done = shade_step<kLds>(ray, depth, closest, hit, pix, smp, a.max_depth, U, s_geom, s_mat, s_aux, a.geom, a.mat, a.aux, stack, sstride, sample, T);
@@ -319,7 +319,6 @@ __global__ void __launch_bounds__(kTraceBlock) RT_TRACE_WAVES(kBvh, kLds) k_trac
     }
 #endif
     // one atomic per wave
-    for (int off = 32; off > 0; off >>= 1) { rays += __shfl_down(rays, off); misses += __shfl_down(misses, off); }
     if (lane == 0 && rays) { atomicAdd(a.ray_counter, (unsigned long long)rays); atomicAdd(a.ray_counter + 1, (unsigned long long)misses); }
 }
 
