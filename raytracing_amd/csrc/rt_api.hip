@@ -46,7 +46,6 @@ int rt_create(int device_ordinal, rt_context** out)
     ctx->device = device_ordinal;
     // RT_AMD_FILTER=disc selects the full-discriminant filter instead of the plane filter (A/B runs).
     { const char* f = getenv("RT_AMD_FILTER"); ctx->plane_filter = !(f && strcmp(f, "disc") == 0); }
-    { const char* f = getenv("RT_AMD_RECORDS"); ctx->records_in_lds = (f && strcmp(f, "lds") == 0); }
     // RT_AMD_TILE_ORDER=image works through the tiles in image order instead of longest-paths-first (A/B runs).
     // RT_AMD_SAMPLE_BUFFER_KB caps the sample buffer (tests use it to run the multi-batch path on small images).
     { const char* f = getenv("RT_AMD_SAMPLE_BUFFER_KB"); const long long kb = f ? atoll(f) : 0; if (kb > 0) ctx->sample_buffer_cap = (uint64_t)kb << 10; }
@@ -69,7 +68,7 @@ void rt_destroy(rt_context* ctx)
     if (ctx->pending) (void)hipStreamSynchronize(ctx->last_stream);
     (void)hipFree(ctx->d_geom); (void)hipFree(ctx->d_mat); (void)hipFree(ctx->d_aux); (void)hipFree(ctx->d_rays); (void)hipFree(ctx->d_ppm_scratch); (void)hipFree(ctx->d_out_rgb); (void)hipFree(ctx->d_out_irgb);
     (void)hipFree(ctx->d_bvh_nodes); (void)hipFree(ctx->d_bvh_leaf); (void)hipFree(ctx->d_bvh_big);
-    (void)hipFree(ctx->d_frec); (void)hipFree(ctx->d_prec); (void)hipFree(ctx->d_samples); (void)hipFree(ctx->d_accum); (void)hipFree(ctx->d_work); (void)hipFree(ctx->d_stacks); (void)hipFree(ctx->d_staging); (void)hipFree(ctx->d_tile_cls); (void)hipFree(ctx->d_tile_order);
+    (void)hipFree(ctx->d_frec); (void)hipFree(ctx->d_prec); (void)hipFree(ctx->d_force); (void)hipFree(ctx->d_samples); (void)hipFree(ctx->d_accum); (void)hipFree(ctx->d_work); (void)hipFree(ctx->d_stacks); (void)hipFree(ctx->d_staging); (void)hipFree(ctx->d_tile_cls); (void)hipFree(ctx->d_tile_order);
     (void)hipFree(ctx->wf_ray); (void)hipFree(ctx->wf_pixsmp); (void)hipFree(ctx->wf_depth); (void)hipFree(ctx->wf_hit_t); (void)hipFree(ctx->wf_hit_idx);
     (void)hipFree(ctx->wf_stacks); (void)hipFree(ctx->wf_q[0]); (void)hipFree(ctx->wf_q[1]); (void)hipFree(ctx->wf_n);
     if (ctx->ev0) (void)hipEventDestroy(ctx->ev0);
@@ -100,19 +99,28 @@ int rt_upload_scene(rt_context* ctx, int n, const float* cx, const float* cy, co
         if ((double)kf > k) kf = nextafterf(kf, -INFINITY);
         frec[i] = make_float4(cx[i], cy[i], cz[i], kf);
     }
-    // Plane-filter records (cx, cz, R_i = r^2 + slack_i, 0).  u = 2^-24.  Allowance for the reference's own
+    // Plane-filter records (cx, cz, 2^88 R_i, 0), R_i = r^2 + slack_i.  u = 2^-24.  Allowance for the reference's own
     // discriminant rounding: 32 u (|o-c|^2 + r^2) <= 64 u (|o|^2 + |c|^2) + 32 u r^2; this form's rounding
     // of pu (< 8 u (|c| + |o|)) moves pu^2 near the threshold by < 16 u |r| (|c| + |o|)
     // <= 8 u (2 r^2 + |c|^2 + |o|^2).  slack_i = u (128 |c|^2 + 64 r^2), S_ray = 128 u |o|^2 (kernel).
+    // The kernel reads the verdict of a pair as the number 0.0 or 1.0, which it is only for 2^-38 <= R_i <= 2^38 (see
+    // filter_bits in rt_sweep.hpp); spheres outside that range -- zero-radius ones included -- get a record that never
+    // passes and a bit in `force`: they always go on to the next test.  Padding records never pass.
     std::vector<float4> prec(n_pad, make_float4(0.0f, 0.0f, -FLT_MAX, 0.0f));
+    std::vector<uint32_t> force((n_pad + 31) / 32, 0u); int n_forced = 0;
     double rmin_R = 1e30;
     for (int i = 0; i < n; ++i) {
         const double rr = (double)radius[i] * radius[i];
         const double cc = (double)cx[i] * cx[i] + (double)cy[i] * cy[i] + (double)cz[i] * cz[i];
         const double R = rr + 5.9604644775390625e-08 * (128.0 * cc + 64.0 * rr) + 1e-30;
         float rf = (float)R; if ((double)rf < R) rf = nextafterf(rf, INFINITY);
-        prec[i] = make_float4(cx[i], cz[i], rr > 1e-12 ? rf : FLT_MAX, 0.0f);     // zero-radius spheres always go to the exact test
-        if (rr > 1e-12 && (double)rf < rmin_R) rmin_R = (double)rf;
+        const bool judged = rf >= 0x1p-38f && rf <= 0x1p38f && std::isfinite(cx[i]) && std::isfinite(cz[i]);
+        if (judged) {
+            prec[i] = make_float4(cx[i], cz[i], ldexpf(rf, 88), 0.0f);
+            if ((double)rf < rmin_R) rmin_R = (double)rf;
+        } else {
+            force[i >> 5] |= 0x80000000u >> (i & 31); ++n_forced;
+        }
     }
     const float plane_s0 = 1e-30f;
     if (rmin_R > 1e29) rmin_R = 1.0;
@@ -126,11 +134,13 @@ int rt_upload_scene(rt_context* ctx, int n, const float* cx, const float* cy, co
     }
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     if (ctx->pending) { HIP_TRY(ctx, hipStreamSynchronize(ctx->last_stream)); ctx->pending = false; }
-    (void)hipFree(ctx->d_geom); (void)hipFree(ctx->d_mat); (void)hipFree(ctx->d_aux); (void)hipFree(ctx->d_frec); (void)hipFree(ctx->d_prec);
-    ctx->d_geom = nullptr; ctx->d_mat = nullptr; ctx->d_aux = nullptr; ctx->d_frec = nullptr; ctx->d_prec = nullptr; ctx->n = 0;
+    (void)hipFree(ctx->d_geom); (void)hipFree(ctx->d_mat); (void)hipFree(ctx->d_aux); (void)hipFree(ctx->d_frec); (void)hipFree(ctx->d_prec); (void)hipFree(ctx->d_force);
+    ctx->d_geom = nullptr; ctx->d_mat = nullptr; ctx->d_aux = nullptr; ctx->d_frec = nullptr; ctx->d_prec = nullptr; ctx->d_force = nullptr; ctx->n = 0;
     HIP_TRY(ctx, hipMalloc(&ctx->d_prec, sizeof(float4) * n_pad));
     HIP_TRY(ctx, hipMemcpy(ctx->d_prec, prec.data(), sizeof(float4) * n_pad, hipMemcpyHostToDevice));
-    ctx->plane_s0 = plane_s0; ctx->plane_rmin = plane_rmin;
+    HIP_TRY(ctx, hipMalloc(&ctx->d_force, sizeof(uint32_t) * force.size()));
+    HIP_TRY(ctx, hipMemcpy(ctx->d_force, force.data(), sizeof(uint32_t) * force.size(), hipMemcpyHostToDevice));
+    ctx->plane_s0 = plane_s0; ctx->plane_rmin = plane_rmin; ctx->n_forced = n_forced;
     HIP_TRY(ctx, hipMalloc(&ctx->d_frec, sizeof(float4) * n_pad));
     HIP_TRY(ctx, hipMemcpy(ctx->d_frec, frec.data(), sizeof(float4) * n_pad, hipMemcpyHostToDevice));
     ctx->n_pad = n_pad;

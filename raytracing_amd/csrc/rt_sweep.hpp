@@ -83,6 +83,7 @@ __device__ __forceinline__ float staged_load(const float* p) { return __hip_atom
 static constexpr int kSuperChunkWords = 16;                     // 32-sphere mask words kept per lane between exact passes (512 spheres)
 static constexpr float kRaySlack = 160.0f * 5.9604645e-08f;   // per-ray slack, relative to |o|^2
 static constexpr float kPlaneRaySlack = 128.0f * 5.9604645e-08f;
+static constexpr float kPlaneScale = 0x1p44f;                   // scaling of the plane filter's per-ray constants; its records carry 2^88 R
 
 // ============================================================================ closest-hit sweep
 // HittableList::Hit (hittablelist.cpp:13-31) over Sphere::Hit (sphere.cpp:15-52) for one ray per lane,
@@ -93,6 +94,8 @@ struct SweepScene {
     const float4* prec;      // plane-filter records (cx, cz, R_i = r^2 + slack_i, 0), same padding
     float plane_s0;          // constant part of the plane filter's per-ray slack
     float plane_rmin;        // smallest R_i over the non-degenerate spheres
+    const uint32_t* force;   // per 32 spheres: bits (31 = first) of the spheres the plane filter does not judge (always candidates)
+    int n_forced;            // how many bits are set in `force`
     const float4* geom;      // exact records in HBM (used when they are not mirrored in LDS)
     int n, n_pad;
 };
@@ -109,8 +112,8 @@ __device__ __forceinline__ float exact_r2(const float4& g, const ExactLds& lds, 
     return g.w;
 }
 
-template <bool kLds, bool kPlane, bool kRecLds, bool kPacked>
-__device__ __forceinline__ void closest_hit(const RayD& ray, float tmin, const SweepScene& sw, const ExactLds& lds, const float4* s_prec,
+template <bool kLds, bool kPlane, bool kPacked>
+__device__ __forceinline__ void closest_hit(const RayD& ray, float tmin, const SweepScene& sw, const ExactLds& lds,
                                             uint32_t* mask_words, float& closest, int& hit, SecTimer& T)
 {
     // Per ray: unit direction (approximate is enough for a conservative test), -(o.d^), 2o,
@@ -143,6 +146,9 @@ __device__ __forceinline__ void closest_hit(const RayD& ray, float tmin, const S
         const float kappa = sqrtf(k2) * (1.0f - 4.0f * 5.9604645e-08f);
         ux *= kappa; uz *= kappa;
         nou = -fmaf(ray.o.x, ux, ray.o.z * uz);
+        // The verdict of a pair is wanted as the number 0.0 or 1.0 (see filter_bits): everything is scaled by 2^44 (exact),
+        // which makes R' - pu'^2 = 2^88 (R - pu^2) either <= 0 or >= 1 for every sphere the host admits to this filter.
+        ux *= kPlaneScale; uz *= kPlaneScale; nou *= kPlaneScale;
     }
     // Filter records are read through the constant address space: the index is wave-uniform,
     // so each record arrives by scalar load in SGPRs and feeds the FMAs as a scalar operand.
@@ -151,31 +157,47 @@ __device__ __forceinline__ void closest_hit(const RayD& ray, float tmin, const S
     const ConstRec frec_k = (ConstRec)(sw.frec);
     const ConstRec prec_k = (ConstRec)(sw.prec);
 
-    // Filter one 32-sphere chunk (or a shorter tail, a multiple of 8): kCount sign bits, left-aligned
-    // (bit 31 = first record of the chunk), 1 = rejected.
+    // Filter one chunk of kCount spheres (32, or 8 / 16 / 24 at the end of the list): candidate bits, left-aligned (bit 31 =
+    // first sphere of the chunk), 1 = may be hit.
+    //
+    // Plane filter: s = R - pu pu, pu = cx ux + (cz uz - o.u), candidate when s > 0.  A sign bit would have to be moved
+    // into a mask by an integer instruction (v_alignbit_b32, four cycles of the vector pipe against two for an FMA).
+    // Instead the third FMA carries the clamp modifier, which is free: with the 2^88 scaling its result is exactly 1.0
+    // for a candidate and 0.0 otherwise (-inf and NaN clamp to 0), and a fourth FMA, acc = 2 acc + s, shifts it into a
+    // float that holds up to sixteen verdicts as an integer.  Why no value falls strictly between 0 and 1: R - pu pu is
+    // formed exactly inside the FMA and is a multiple of min(ulp(R), ulp(pu)^2); it can only be small when pu^2 is
+    // close to R, and for 2^-38 <= R <= 2^38 that puts both granules at 2^-88 or more, so a positive difference is at
+    // least 2^-88, i.e. at least 1 after scaling.  Spheres outside that range of R (and zero-radius ones) are not
+    // judged here at all: the host gives them a record that never passes and sets their bit in `force`.
+    // s = 0 exactly (pu^2 equal to the inflated threshold) counts as a miss, which the margin inside R allows.
     auto filter_bits = [&](int base, auto count_tag) -> uint32_t {
         constexpr int kCount = decltype(count_tag)::value;
+        if (kPlane) {
+            float acc0 = 0.0f, acc1 = 0.0f;
+#pragma unroll
+            for (int jj = 0; jj < kCount; ++jj) {
+                const f4v f = prec_k[base + jj];
+                const float pu = fmaf(f.x, ux, fmaf(f.y, uz, nou));
+                float verdict;
+                asm("v_fma_f32 %0, -%1, %1, %2 clamp" : "=v"(verdict) : "v"(pu), "s"(f.z));
+                if (jj < 16) acc0 = fmaf(acc0, 2.0f, verdict); else acc1 = fmaf(acc1, 2.0f, verdict);
+            }
+            const uint32_t bits = kCount > 16 ? ((uint32_t)acc0 << (kCount > 16 ? kCount - 16 : 0)) | (uint32_t)acc1 : (uint32_t)acc0;
+            return bits << (32 - kCount);
+        }
         uint32_t mask = 0u;
 #pragma unroll
         for (int jj = 0; jj < kCount; ++jj) {
-            float sgn;
-            if (kPlane) {
-                float fx, fy, fz;
-                if (kRecLds) { const float4 f = s_prec[base + jj]; fx = f.x; fy = f.y; fz = f.z; }
-                else { const f4v f = prec_k[base + jj]; fx = f.x; fy = f.y; fz = f.z; }
-                const float pu = fmaf(fx, ux, fmaf(fy, uz, nou));
-                sgn = fmaf(-pu, pu, fz);
-            } else {
-                const f4v f = frec_k[base + jj];
-                const float b = fmaf(f.x, hx, fmaf(f.y, hy, fmaf(f.z, hz, nod)));
-                const float w = fmaf(f.x, p2x, fmaf(f.y, p2y, fmaf(f.z, p2z, noo)));
-                const float e = fmaf(b, b, w);
-                sgn = e - f.w;
-            }
-            mask = __builtin_amdgcn_alignbit(mask, __float_as_uint(sgn), 31);   // append sign bit
+            const f4v f = frec_k[base + jj];
+            const float b = fmaf(f.x, hx, fmaf(f.y, hy, fmaf(f.z, hz, nod)));
+            const float w = fmaf(f.x, p2x, fmaf(f.y, p2y, fmaf(f.z, p2z, noo)));
+            const float e = fmaf(b, b, w);
+            mask = __builtin_amdgcn_alignbit(mask, __float_as_uint(e - f.w), 31);   // append sign bit, 1 = rejected
         }
-        return mask;
+        return ~mask << (32 - kCount);
     };
+    typedef const __attribute__((address_space(4))) uint32_t* ConstWord;
+    const ConstWord force_k = (ConstWord)(sw.force);
 
     T.mark(1);
     // Super-chunks of up to 16 mask words (512 spheres).  The filter only stores each word and notes
@@ -188,19 +210,27 @@ __device__ __forceinline__ void closest_hit(const RayD& ray, float tmin, const S
         int base = sbase;
         const int send = (sw.n_pad - sbase < 32 * kSuperChunkWords) ? sw.n_pad : sbase + 32 * kSuperChunkWords;
         for (; base + 32 <= send; base += 32, ++words) {
-            const uint32_t cand = ~filter_bits(base, std::integral_constant<int, 32>());
+            const uint32_t cand = filter_bits(base, std::integral_constant<int, 32>());
             mask_words[words * 64] = cand;
             nz = __builtin_amdgcn_alignbit(nz, cand | (0u - cand), 31);
         }
         if (base < send) {         // tail: 8, 16 or 24 records
-            uint32_t m = 0u; int got = 0;
-            for (; base < send; base += 8, got += 8) m = (m << 8) | filter_bits(base, std::integral_constant<int, 8>());
-            const uint32_t cand = (~m) << (32 - got);
+            const int got = send - base;
+            const uint32_t cand = got == 8 ? filter_bits(base, std::integral_constant<int, 8>())
+                                : got == 16 ? filter_bits(base, std::integral_constant<int, 16>()) : filter_bits(base, std::integral_constant<int, 24>());
+            base = send;
             mask_words[words * 64] = cand;
             nz = __builtin_amdgcn_alignbit(nz, cand | (0u - cand), 31);
             ++words;
         }
         nz <<= (32 - words);
+        // spheres the plane filter does not judge (none in ordinary scenes): their bits are added here, outside the hot loop
+        if (kPlane && sw.n_forced > 0) {
+            for (int w = 0; w < words; ++w) {
+                const uint32_t f = force_k[(sbase >> 5) + w];
+                if (f != 0u) { mask_words[w * 64] |= f; nz |= 0x80000000u >> w; }
+            }
+        }
         T.mark(1);
         // Pass A: every survivor of the plane filter goes through the discriminant filter (the 8-FMA form
         // above, on the same per-ray constants and the per-sphere constant k; it never rejects a sphere

@@ -23,7 +23,8 @@
 //            follow hittablelist.cpp:13-31, so the chosen sphere and t are bit-identical.
 // A wave left with only a few live paths (the end of a launch) switches to closest_hit_few.
 struct TraceArgs {
-    const float4* prec;      // plane-filter records (cx, cz, R_i = r^2 + slack_i, 0), same padding as frec
+    const float4* prec;      // plane-filter records (cx, cz, 2^88 R_i, 0), R_i = r^2 + slack_i, same padding as frec
+    const uint32_t* force; int n_forced;   // per 32 spheres: the ones the plane filter does not judge (see closest_hit), and their number
     float plane_s0, plane_rmin;   // plane filter: constant part of the per-ray slack, smallest R_i
     const float4* frec;      // discriminant-filter records (cx, cy, cz, |c|^2 - r^2 - slack), padded to a multiple of 8
     const float4* geom; const float4* mat; const Aux* aux; int n, n_pad;
@@ -144,7 +145,7 @@ __global__ void __launch_bounds__(1024) k_tile_order(const TileArgs a)
 #else
 #define RT_TRACE_WAVES(kBvh, kLds) __attribute__((amdgpu_waves_per_eu((kBvh) && (kLds) ? 4 : 6, (kBvh) && (kLds) ? 4 : 6)))
 #endif
-template <bool kLds, bool kPlane, bool kRecLds = false, bool kBvh = false>
+template <bool kLds, bool kPlane, bool kBvh = false>
 __global__ void __launch_bounds__(kTraceBlock) RT_TRACE_WAVES(kBvh, kLds) k_trace(const TraceArgs a)
 {
     extern __shared__ float4 smem[];
@@ -163,10 +164,6 @@ __global__ void __launch_bounds__(kTraceBlock) RT_TRACE_WAVES(kBvh, kLds) k_trac
     // (In RT_MODE_BVH the same area holds each lane's stack of pending nodes instead.)
     constexpr int kWordsPerLane = kBvh ? kBvhStack : kSuperChunkWords;
     uint32_t* mask_words = reinterpret_cast<uint32_t*>(lds_after_scene) + (size_t)wave * kWordsPerLane * 64 + lane;
-    // Measurement variant (kRecLds): plane-filter records mirrored in LDS and read by broadcast ds_read_b128
-    // instead of by scalar load.
-    float4* s_prec = reinterpret_cast<float4*>(lds_after_scene + (size_t)(kTraceBlock / 64) * kWordsPerLane * 64 * sizeof(uint32_t));
-    if (kRecLds) { for (int i = threadIdx.x; i < a.n_pad; i += kTraceBlock) s_prec[i] = a.prec[i]; }
     __syncthreads();
     // The recursion's attenuation chain is replayed innermost-first when a path reaches the sky, so
     // each lane keeps the indices of the spheres it bounced off.  One 2-byte store per bounce and a
@@ -188,7 +185,7 @@ __global__ void __launch_bounds__(kTraceBlock) RT_TRACE_WAVES(kBvh, kLds) k_trac
     SecTimer T; T.start();
     ItemGeometry ig; ig.width = a.width; ig.height = a.height; ig.band_rows = a.band_rows; ig.band_first = a.band_first; ig.band_step = a.band_step;
     ig.owned_rows = a.owned_rows; ig.tiles_x = a.tiles_x; ig.Q = a.Q; ig.s_begin = a.s_begin; ig.s_count = a.s_count; ig.tile_order = a.tile_order;
-    SweepScene sw; sw.frec = a.frec; sw.prec = a.prec; sw.plane_s0 = a.plane_s0; sw.plane_rmin = a.plane_rmin; sw.geom = a.geom; sw.n = a.n; sw.n_pad = a.n_pad;
+    SweepScene sw; sw.frec = a.frec; sw.prec = a.prec; sw.force = a.force; sw.n_forced = a.n_forced; sw.plane_s0 = a.plane_s0; sw.plane_rmin = a.plane_rmin; sw.geom = a.geom; sw.n = a.n; sw.n_pad = a.n_pad;
 
 #ifdef RT_WAVE_TIMELINE
     const unsigned long long t_enter = __builtin_amdgcn_s_memrealtime(); unsigned long long t_dry = 0, trips_dry = 0, sparse_trips = 0, sparse_ticks = 0, t_trip = 0, t_first_sweep = 0, t_first_done = 0; bool was_sparse = false;
@@ -296,7 +293,7 @@ __global__ void __launch_bounds__(kTraceBlock) RT_TRACE_WAVES(kBvh, kLds) k_trac
 #endif
         if (kBvh) { if (active) closest_hit_bvh<kLds>(ray, a.tmin, a.bvh, exact_lds, mask_words, closest, hit); }
         else if (__popcll(live) <= kFewPaths) closest_hit_few<kLds>(ray, a.tmin, sw, exact_lds, live, lane, closest, hit);
-        else if (active) closest_hit<kLds, kPlane, kRecLds, true>(ray, a.tmin, sw, exact_lds, s_prec, mask_words, closest, hit, T);
+        else if (active) closest_hit<kLds, kPlane, true>(ray, a.tmin, sw, exact_lds, mask_words, closest, hit, T);
         rays += (uint32_t)__popcll(live); misses += (uint32_t)__popcll(__ballot(active && hit < 0));
         if (active) {
             T.mark(4);
@@ -367,8 +364,7 @@ namespace {
 using TraceKernel = void (*)(const TraceArgs);
 TraceKernel trace_kernel(const TracePlan& t)
 {
-    if (t.bvh) return t.lds ? k_trace<true, true, false, true> : k_trace<false, true, false, true>;
-    if (t.reclds) return k_trace<true, true, true>;
+    if (t.bvh) return t.lds ? k_trace<true, true, true> : k_trace<false, true, true>;
     if (t.lds) return t.plane ? k_trace<true, true> : k_trace<true, false>;
     return t.plane ? k_trace<false, true> : k_trace<false, false>;
 }
@@ -384,10 +380,8 @@ int trace_prepare(rt_context* ctx, const RenderFrame& f, TracePlan* plan)
     t.lds = ctx->n <= kMaxLdsSpheres;
     t.plane = ctx->plane_filter;
     t.bvh = p->mode == RT_MODE_BVH;
-    t.reclds = !t.bvh && ctx->records_in_lds && t.lds && t.plane && ctx->n_pad <= 2048;
-    t.shmem = (t.lds ? (size_t)ctx->n * kLdsBytesPerSphere : 0) + (size_t)(kTraceBlock / 64) * (t.bvh ? kBvhStack : kSuperChunkWords) * 64 * sizeof(uint32_t) +
-              (t.reclds ? (size_t)ctx->n_pad * sizeof(float4) : 0);
-    int& bpc = ctx->trace_blocks_per_cu[t.bvh ? (t.lds ? 6 : 5) : t.reclds ? 4 : (t.lds ? 1 : 0) + (t.plane ? 2 : 0)];
+    t.shmem = (t.lds ? (size_t)ctx->n * kLdsBytesPerSphere : 0) + (size_t)(kTraceBlock / 64) * (t.bvh ? kBvhStack : kSuperChunkWords) * 64 * sizeof(uint32_t);
+    int& bpc = ctx->trace_blocks_per_cu[t.bvh ? (t.lds ? 5 : 4) : (t.lds ? 1 : 0) + (t.plane ? 2 : 0)];
     if (bpc == 0) {
         int nb = 0;
         hipError_t e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, trace_kernel(t), kTraceBlock, t.shmem);
@@ -432,7 +426,7 @@ int trace_batch(rt_context* ctx, const RenderFrame& f, const TracePlan& t, const
 {
     const rt_params* p = f.p;
     TraceArgs a;
-    a.prec = ctx->d_prec; a.plane_s0 = ctx->plane_s0; a.plane_rmin = ctx->plane_rmin; a.frec = ctx->d_frec; a.geom = ctx->d_geom; a.mat = ctx->d_mat; a.aux = ctx->d_aux; a.n = ctx->n; a.n_pad = ctx->n_pad; a.cam = ctx->cam;
+    a.prec = ctx->d_prec; a.force = ctx->d_force; a.n_forced = ctx->n_forced; a.plane_s0 = ctx->plane_s0; a.plane_rmin = ctx->plane_rmin; a.frec = ctx->d_frec; a.geom = ctx->d_geom; a.mat = ctx->d_mat; a.aux = ctx->d_aux; a.n = ctx->n; a.n_pad = ctx->n_pad; a.cam = ctx->cam;
     a.width = p->width; a.height = p->height; a.max_depth = p->max_depth; a.tmin = p->tmin;
     a.k0 = (uint32_t)p->seed; a.k1 = (uint32_t)(p->seed >> 32);
     a.band_rows = p->band_rows; a.band_first = p->band_first; a.band_step = p->band_step; a.owned_rows = f.owned;

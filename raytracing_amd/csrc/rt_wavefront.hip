@@ -61,7 +61,7 @@ __global__ void __launch_bounds__(kTraceBlock) k_wf_intersect(const WfArgs a)
         ray.o = mk(a.ray[0 * (size_t)a.P + s], a.ray[1 * (size_t)a.P + s], a.ray[2 * (size_t)a.P + s]);
         ray.d = mk(a.ray[3 * (size_t)a.P + s], a.ray[4 * (size_t)a.P + s], a.ray[5 * (size_t)a.P + s]);
         float closest = FLT_MAX; int hit = -1;
-        if (a.pixsmp[s] != 0xffffffffu) closest_hit<kLds, kPlane, false, false>(ray, a.tmin, a.sw, ExactLds{ s_geom, nullptr, s_disck }, nullptr, mask_words, closest, hit, T);
+        if (a.pixsmp[s] != 0xffffffffu) closest_hit<kLds, kPlane, false>(ray, a.tmin, a.sw, ExactLds{ s_geom, nullptr, s_disck }, mask_words, closest, hit, T);
         a.hit_t[s] = closest; a.hit_idx[s] = hit;
     }
 }
@@ -181,7 +181,7 @@ int wavefront_batch(rt_context* ctx, const RenderFrame& f, const SampleBatch& b)
         ctx->wf_P = P;
     }
     WfArgs w;
-    w.sw.frec = ctx->d_frec; w.sw.prec = ctx->d_prec; w.sw.plane_s0 = ctx->plane_s0; w.sw.plane_rmin = ctx->plane_rmin; w.sw.geom = ctx->d_geom; w.sw.n = ctx->n; w.sw.n_pad = ctx->n_pad;
+    w.sw.frec = ctx->d_frec; w.sw.prec = ctx->d_prec; w.sw.force = ctx->d_force; w.sw.n_forced = ctx->n_forced; w.sw.plane_s0 = ctx->plane_s0; w.sw.plane_rmin = ctx->plane_rmin; w.sw.geom = ctx->d_geom; w.sw.n = ctx->n; w.sw.n_pad = ctx->n_pad;
     w.mat = ctx->d_mat; w.aux = ctx->d_aux; w.cam = ctx->cam;
     w.ig.width = p->width; w.ig.height = p->height; w.ig.band_rows = p->band_rows; w.ig.band_first = p->band_first; w.ig.band_step = p->band_step;
     w.ig.owned_rows = f.owned; w.ig.tiles_x = f.tiles_x; w.ig.Q = (uint32_t)f.Q; w.ig.s_begin = b.s0; w.ig.s_count = b.sc; w.ig.tile_order = nullptr;

@@ -473,6 +473,38 @@ def test_random_scenes_match_oracle_in_all_modes(rt):
             assert np.array_equal(irgb, wq), (case, n, mode)
 
 
+def test_extreme_radii_match_oracle_in_all_modes(rt):
+    """Radii far outside the ordinary range: points (r = 0), specks of 1e-9 .. 1e-5, spheres of 6e5 and 1e7 units (the
+    kernels' plane filter does not judge such spheres itself and must pass them on), mixed with ordinary ones, seen from
+    near and from far away.  Every kernel organisation against the CPU oracle, bit for bit."""
+    rng = np.random.default_rng(77)
+    W, H, S = 40, 24, 3
+    for case, n in enumerate([6, 40, 70, 300]):
+        table = _random_scene(rng, n)
+        odd = rng.choice(n, size=max(3, n // 4), replace=False)
+        table[odd, 3] = rng.choice([0.0, 1e-9, 1e-7, 1e-5, -1e-6, 6e5, 1e7], size=len(odd))
+        big = np.abs(table[:, 3]) > 1e3
+        table[big, 1] = -np.abs(table[big, 3]) - rng.uniform(0.0, 2.0, size=big.sum())      # huge ones below the scene, like a ground
+        table = np.asarray(table, dtype=np.float32).astype(np.float64)
+        dist = float(rng.choice([3.0, 8.0, 500.0]))
+        direction = rng.normal(size=3); direction[1] = abs(direction[1]) + 0.2; direction /= np.linalg.norm(direction)
+        ocam = O.make_camera(direction * dist, (0.0, 0.0, 0.0), (0.0, 1.0, 0.0), 40.0 if dist < 100 else 1.5, np.float32(W) / np.float32(H), 0.0, dist)
+        pod = R.CameraPod()
+        for dst, src in (("origin", "origin"), ("lower_left_corner", "llc"), ("horizontal", "horiz"), ("vertical", "vert"), ("u", "u"), ("v", "v"), ("w", "w")):
+            vec = getattr(ocam, src)
+            getattr(pod, dst)[:] = [vec.x, vec.y, vec.z]
+        pod.lens_radius = ocam.lens_radius
+        rt.upload_scene(table)
+        rt.set_camera(pod)
+        seed = 4000 + case
+        want, wq, wrays, wcount = O.render_counted(O.SceneArrays.from_table(table), ocam, W, H, S, O.usrc_philox(seed))
+        for mode in (R.MODE_MEGAKERNEL, R.MODE_WAVEFRONT, R.MODE_PIXEL, R.MODE_BVH):
+            rgb, irgb, rays, _ = rt.render(rt.params(W, H, S, seed=seed, mode=mode))
+            assert rays == wrays, (case, n, mode)
+            assert mismatch(rgb, want) == 0, (case, n, mode, mismatch(rgb, want))
+            assert np.array_equal(irgb, wq), (case, n, mode)
+
+
 def test_tile_work_order_is_invisible_and_follows_scene_camera_and_rows(rt, monkeypatch):
     """The order in which tiles are worked on (longest paths first, kept between calls) never shows in the image:
     same bits as the image-order variant, and a new camera, scene or row selection is picked up by the next call."""

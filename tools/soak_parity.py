@@ -20,6 +20,7 @@ def random_scene(rng, n):
             t[k, 8] = rng.choice([1.5, 0.8, 1.0, 2.4]); t[k, 5:8] = 1.0
             if rng.random() < 0.4: t[k, 3] = -t[k, 3]
         if k > 0 and rng.random() < 0.1: t[k, 0:4] = t[rng.integers(0, k), 0:4]
+        if rng.random() < 0.03: t[k, 3] = rng.choice([0.0, 1e-9, 1e-6, 2e-6, 4e-6, 5e5, 6e5, 1e7])     # outside what the plane filter judges itself
     if n > 3 and rng.random() < 0.5: t[0] = [0.0, -1000.0, 0.0, 1000.0, R.LAMBERTIAN, 0.5, 0.5, 0.5, 0.0]
     return np.asarray(t, dtype=np.float32).astype(np.float64), spread
 
