@@ -106,7 +106,10 @@ int64_t rt_owned_pixels(const rt_params *p);
 /* Device-pointer form.  d_rgb_mean: 3 floats per owned pixel, the per-pixel mean `col / ns`
  * before gamma (main.cpp:135); d_irgb: 3 int32 per owned pixel, int(255.99*sqrt(mean))
  * (main.cpp:136-140).  Either may be NULL.  Work is enqueued on `stream` (a hipStream_t; NULL =
- * the default stream) and the call returns without waiting. */
+ * the default stream) and the call returns without waiting, with two exceptions: a call that needs
+ * larger internal buffers than the one before waits for the stream before it reallocates them, and
+ * RT_MODE_WAVEFRONT steers its bounce loop from the host (it reads the number of live paths back every
+ * eight bounces). */
 int rt_render_device(rt_context *ctx, const rt_params *p, float *d_rgb_mean, int32_t *d_irgb,
                      void *stream);
 /* Waits for the last rt_render_device on ctx and reports the closest-hit queries it traced (one
