@@ -251,7 +251,7 @@ __device__ __forceinline__ void closest_hit(const RayD& ray, float tmin, const S
             for (;;) {
                 const int jj = __builtin_clz(cand);
                 const uint32_t bit = 0x80000000u >> jj;
-                cand &= ~bit;
+                cand ^= bit;                   // the bit is set: a two-cycle xor instead of a four-cycle and-not
                 const int k = cbase + jj;
                 const float4 g = kLds ? lds.geom[k] : sw.geom[k];
                 const float dk = !kLds ? sw.frec[k].w : kPacked ? g.w : lds.disck[k];
@@ -279,7 +279,7 @@ __device__ __forceinline__ void closest_hit(const RayD& ray, float tmin, const S
             int cbase = sbase + (w << 5);
             for (;;) {
                 const int jj = __builtin_clz(cand);
-                cand &= ~(0x80000000u >> jj);
+                cand ^= 0x80000000u >> jj;
                 const int k = cbase + jj;
                 const float4 g = kLds ? lds.geom[k] : sw.geom[k];
                 const V3 oc = ray.o - mk(g.x, g.y, g.z);
