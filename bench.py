@@ -149,6 +149,14 @@ def main():
         multi = cpu_baseline_multicore(1200, 800, 10, min(16, os.cpu_count() or 1))
         if multi:
             cpu_lines["cpu_baseline_multicore"] = multi
+    # Full-size parity: a few rows of the 1200x800 image from the reference's own code on the keyed stream (a child process,
+    # about a second of CPU), compared bit for bit with the GPU's rows further down.
+    ref_rows = None
+    if world == 1 and not args.no_cpu_baseline and WORKLOADS[args.workload][:3] == ("final", 1200, 800):
+        sys.path.insert(0, os.path.join(ROOT, "oracle"))
+        import ref_band
+        if ref_band.exact_available():
+            ref_rows = (396, 8, 4) + ref_band.keyed_band_exact(1200, 800, 4, 396, 8, args.seed)       # j0, rows, spp, image, rays
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the render path has no CPU fallback")
     if args.rehearse_on_one_gpu:
@@ -260,6 +268,14 @@ def main():
                                 "kernel": "k_trace (hierarchy walk)",
                                 "note": "optional mode beyond the brute-force sweep: per-lane tree walk, latency-bound; compare ms_per_step with the megakernel's"}
         line.update(cpu_lines)
+        if ref_rows is not None:
+            j0, nrows, cspp, want, _ = ref_rows
+            got, _, _, _ = rt.render(rt.params(width, height, cspp, seed=args.seed, mode=mode))
+            band = got[height - (j0 + nrows):height - j0]
+            same = (band.view(np.uint32) == want.view(np.uint32)) | (np.isnan(band) & np.isnan(want))
+            line["parity_at_full_size"] = {"identical": bool(same.all()), "differing_values": int((~same).sum()),
+                                           "what": f"rows {height - (j0 + nrows)}..{height - j0} of {width}x{height} at {cspp} spp, seed {args.seed}: linear RGB floats of this "
+                                                   "library against the reference's own code (pinned build, no FMA contraction) on the same keyed random stream"}
         checksum = int(img.to(torch.int64).sum().item()) if img is not None else None
         line["image_checksum"] = checksum
         if img is not None and img.is_cuda:

@@ -7,6 +7,7 @@ results (1e-5 relative) is therefore met with margin and is only invoked where a
 import ctypes as C
 import json
 import os
+import sys
 
 import numpy as np
 import pytest
@@ -471,6 +472,24 @@ def test_random_scenes_match_oracle_in_all_modes(rt):
             assert rt.counters() == wcount, (case, n, mode)
             assert mismatch(rgb, want) == 0, (case, n, mode, mismatch(rgb, want))
             assert np.array_equal(irgb, wq), (case, n, mode)
+
+
+def test_full_size_rows_match_the_reference_build(rt):
+    """Rows of the 1200x800 image (the size the benchmark is quoted on) rendered by the reference's own code -- the pinned build
+    oracle/_ref/ref_harness, compiled from the reference's sources where they lie -- on the keyed stream, against every kernel
+    organisation, bit for bit.  Skipped where that build is not present."""
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "oracle"))
+    import ref_band
+    if not ref_band.exact_available():
+        pytest.skip("oracle/_ref/ref_harness not built")
+    W, H, S, seed = 1200, 800, 3, 5
+    rt.upload_scene(R.final_scene_table())
+    rt.set_camera(R.final_camera(W, H))
+    bands = [(j0, 4) + ref_band.keyed_band_exact(W, H, S, j0, 4, seed) for j0 in (398, 520, 120)]      # spheres, horizon, foreground
+    for mode in (R.MODE_MEGAKERNEL, R.MODE_BVH, R.MODE_WAVEFRONT, R.MODE_PIXEL):
+        rgb, _, _, _ = rt.render(rt.params(W, H, S, seed=seed, mode=mode))
+        for j0, rows, want, _ in bands:
+            assert mismatch(rgb[H - (j0 + rows):H - j0], want) == 0, (mode, j0)
 
 
 def test_extreme_radii_match_oracle_in_all_modes(rt):
