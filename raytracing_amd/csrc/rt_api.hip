@@ -107,20 +107,33 @@ int rt_upload_scene(rt_context* ctx, int n, const float* cx, const float* cy, co
     // filter_bits in rt_sweep.hpp); spheres outside that range -- zero-radius ones included -- get a record that never
     // passes and a bit in `force`: they always go on to the next test.  Padding records never pass.
     std::vector<float4> prec(n_pad, make_float4(0.0f, 0.0f, -FLT_MAX, 0.0f));
-    std::vector<uint32_t> force((n_pad + 31) / 32, 0u); int n_forced = 0;
+    const int n_words = (n_pad + 31) / 32;
+    std::vector<uint32_t> force(n_words + (n_words + 15) / 16, 0u); int n_forced = 0;      // forced bits, then one "stored normalised" bit per chunk
+    std::vector<float> Rof(n_pad, 0.0f); std::vector<char> judged_flag(n_pad, 0);
     double rmin_R = 1e30;
     for (int i = 0; i < n; ++i) {
         const double rr = (double)radius[i] * radius[i];
         const double cc = (double)cx[i] * cx[i] + (double)cy[i] * cy[i] + (double)cz[i] * cz[i];
-        const double R = rr + 5.9604644775390625e-08 * (128.0 * cc + 64.0 * rr) + 1e-30;
+        const double R = rr + 5.9604644775390625e-08 * (144.0 * cc + 80.0 * rr) + 1e-30;
         float rf = (float)R; if ((double)rf < R) rf = nextafterf(rf, INFINITY);
         const bool judged = rf >= 0x1p-38f && rf <= 0x1p38f && std::isfinite(cx[i]) && std::isfinite(cz[i]);
+        Rof[i] = rf; judged_flag[i] = judged ? 1 : 0;
         if (judged) {
             prec[i] = make_float4(cx[i], cz[i], ldexpf(rf, 88), 0.0f);
             if ((double)rf < rmin_R) rmin_R = (double)rf;
         } else {
             force[i >> 5] |= 0x80000000u >> (i & 31); ++n_forced;
         }
+    }
+    // Full chunks of 32 judged spheres whose R lie within 20 % of each other are stored normalised by rho = sqrt(max R)
+    // (rounded up): (cx / rho, cz / rho, 1 / rho, 0); see filter_norm in rt_sweep.hpp.
+    for (int base = 0; base + 32 <= n_pad && base + 32 <= n; base += 32) {
+        float rmax = 0.0f, rmin = FLT_MAX; bool all = true;
+        for (int i = base; i < base + 32; ++i) { all = all && judged_flag[i]; rmax = std::max(rmax, Rof[i]); rmin = std::min(rmin, Rof[i]); }
+        if (!all || rmin < 0.8f * rmax) continue;
+        const double rho = std::sqrt((double)rmax) * (1.0 + 1e-7);
+        for (int i = base; i < base + 32; ++i) prec[i] = make_float4((float)(cx[i] / rho), (float)(cz[i] / rho), (float)(1.0 / rho), 0.0f);
+        force[n_words + (base >> 9)] |= 0x8000u >> ((base >> 5) & 15);
     }
     const float plane_s0 = 1e-30f;
     if (rmin_R > 1e29) rmin_R = 1.0;

@@ -492,6 +492,38 @@ def test_full_size_rows_match_the_reference_build(rt):
             assert mismatch(rgb[H - (j0 + rows):H - j0], want) == 0, (mode, j0)
 
 
+def test_equal_radii_scenes_match_oracle_in_all_modes(rt):
+    """Scenes whose spheres (nearly) all have the same radius: the plane filter stores whole chunks of 32 such spheres in a
+    normalised form with one threshold for the chunk.  Equal, nearly equal (within 0.1 % and within 10 %) and equal with a
+    few odd ones mixed in; every kernel organisation against the CPU oracle, bit for bit."""
+    rng = np.random.default_rng(4242)
+    W, H, S = 40, 24, 3
+    for case, (n, spread_r) in enumerate([(64, 0.0), (200, 0.001), (513, 0.1), (96, 0.0)]):
+        table = _random_scene(rng, n)
+        r0 = float(rng.choice([0.05, 0.2, 0.6]))
+        sign = np.sign(table[:, 3])
+        table[:, 3] = sign * r0 * (1.0 - spread_r * rng.random(n))
+        if case == 3:
+            table[rng.choice(n, size=5, replace=False), 3] = [1.5, 0.01, 3.0, 0.0, 0.2]      # chunks with odd ones stay in the plain form
+        table = np.asarray(table, dtype=np.float32).astype(np.float64)
+        look_from = rng.uniform(-5.0, 5.0, size=3)
+        ocam = O.make_camera(look_from, rng.uniform(-1.0, 1.0, size=3), (0.0, 1.0, 0.0), float(rng.choice([30.0, 80.0])), np.float32(W) / np.float32(H), float(rng.choice([0.0, 0.2])), 4.0)
+        pod = R.CameraPod()
+        for dst, src in (("origin", "origin"), ("lower_left_corner", "llc"), ("horizontal", "horiz"), ("vertical", "vert"), ("u", "u"), ("v", "v"), ("w", "w")):
+            vec = getattr(ocam, src)
+            getattr(pod, dst)[:] = [vec.x, vec.y, vec.z]
+        pod.lens_radius = ocam.lens_radius
+        rt.upload_scene(table)
+        rt.set_camera(pod)
+        seed = 6000 + case
+        want, wq, wrays, wcount = O.render_counted(O.SceneArrays.from_table(table), ocam, W, H, S, O.usrc_philox(seed))
+        for mode in (R.MODE_MEGAKERNEL, R.MODE_WAVEFRONT, R.MODE_PIXEL, R.MODE_BVH):
+            rgb, irgb, rays, _ = rt.render(rt.params(W, H, S, seed=seed, mode=mode))
+            assert rays == wrays, (case, n, mode)
+            assert mismatch(rgb, want) == 0, (case, n, mode, mismatch(rgb, want))
+            assert np.array_equal(irgb, wq), (case, n, mode)
+
+
 def test_extreme_radii_match_oracle_in_all_modes(rt):
     """Radii far outside the ordinary range: points (r = 0), specks of 1e-9 .. 1e-5, spheres of 6e5 and 1e7 units (the
     kernels' plane filter does not judge such spheres itself and must pass them on), mixed with ordinary ones, seen from

@@ -12,6 +12,8 @@ def random_scene(rng, n):
     spread = rng.choice([1.0, 3.0, 12.0, 80.0])
     t[:, 0:3] = rng.uniform(-spread, spread, size=(n, 3))
     t[:, 3] = np.exp(rng.uniform(np.log(0.01), np.log(0.6 * spread), size=n))
+    if rng.random() < 0.4:        # (nearly) equal radii: whole chunks of 32 then take the filter's normalised form
+        t[:, 3] = float(np.exp(rng.uniform(np.log(0.02), np.log(0.3 * spread)))) * rng.uniform(rng.choice([0.9, 0.999, 1.0]), 1.0, size=n)
     t[:, 4] = rng.integers(0, 3, size=n)
     t[:, 5:8] = rng.uniform(0.05, 1.0, size=(n, 3))
     for k in range(n):
