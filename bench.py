@@ -33,7 +33,7 @@ FLOP_PER_TEST = 18                 # oc (3) + oc.d (5) + oc.oc (5) + -r^2 (1) + 
 FLOP_PER_RAY_EXTRA = 150           # hit resolve + scatter, per closest-hit query
 # HBM bytes per ray of the render kernels from rocprofv3 FETCH_SIZE (x2, the gfx950 correction for coalesced reads) + WRITE_SIZE
 # (profiles/r01_pmc_traffic.txt); a profiled constant, not measured inside this script
-HBM_BYTES_PER_RAY_PMC = 44.6
+HBM_BYTES_PER_RAY_PMC = 44.9
 
 WORKLOADS = {
     # name: (scene, width, height, spp)
