@@ -102,7 +102,8 @@ int rt_upload_scene(rt_context* ctx, int n, const float* cx, const float* cy, co
     // Plane-filter records (cx, cz, 2^88 R_i, 0), R_i = r^2 + slack_i.  u = 2^-24.  Allowance for the reference's own
     // discriminant rounding: 32 u (|o-c|^2 + r^2) <= 64 u (|o|^2 + |c|^2) + 32 u r^2; this form's rounding
     // of pu (< 8 u (|c| + |o|)) moves pu^2 near the threshold by < 16 u |r| (|c| + |o|)
-    // <= 8 u (2 r^2 + |c|^2 + |o|^2).  slack_i = u (128 |c|^2 + 64 r^2), S_ray = 128 u |o|^2 (kernel).
+    // <= 8 u (2 r^2 + |c|^2 + |o|^2); the normalised form of a chunk (below) adds the roundings of cx / rho, cz / rho
+    // and (o.u) / rho, another 5 u (|c| + |o|) on pu.  slack_i = u (144 |c|^2 + 80 r^2), S_ray = 144 u |o|^2 (kernel).
     // The kernel reads the verdict of a pair as the number 0.0 or 1.0, which it is only for 2^-38 <= R_i <= 2^38 (see
     // filter_bits in rt_sweep.hpp); spheres outside that range -- zero-radius ones included -- get a record that never
     // passes and a bit in `force`: they always go on to the next test.  Padding records never pass.
