@@ -191,6 +191,11 @@ int rt_test_scatter(rt_context *ctx, int n, const int32_t *material, const float
 /* Camera::GetRay (camera.cpp:46-53) with an explicit unit-disk sample per case. */
 int rt_test_get_ray(rt_context *ctx, int n, const rt_camera_pod *cam, const float *s,
                     const float *t, const float *disk_xy, float *ray_o, float *ray_d);
+/* Reflect, Refract and Schlick (material.h:35-38, 16-33, 7-14) on arrays: v[3n], normal[3n], ni_over_nt[n], cosine[n],
+ * ref_idx[n] -> reflected[3n], refract_ok[n], refracted[3n] (zeros where Refract fails), schlick[n]. */
+int rt_test_helpers(rt_context *ctx, int n, const float *v, const float *normal, const float *ni_over_nt,
+                    const float *cosine, const float *ref_idx, float *reflected, int32_t *refract_ok,
+                    float *refracted, float *schlick);
 /* Philox4x32-10 blocks: ctr[4n], key[2] -> out[4n]. */
 int rt_test_philox(rt_context *ctx, int n, const uint32_t *ctr, const uint32_t *key, uint32_t *out);
 

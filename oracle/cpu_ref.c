@@ -248,6 +248,39 @@ void orc_quantise(const float m[3], int out[3])                                 
     }
 }
 
+/* ------------------------------------------------------------------ the reference's lens generator (camera.cpp:33-35)
+ * std::mt19937 and std::uniform_real_distribution<float>(0, 1) as libstdc++ 11 implements them (the reference names only
+ * the standard classes; MT19937 is Matsumoto & Nishimura's published generator, and the distribution is
+ * generate_canonical<float, 24>: one 32-bit draw converted to float, divided by 2^32, and a result that rounds up to 1
+ * replaced by the float below 1).  Off by default; orc_lens_mt19937(1, seed) makes the non-keyed sources of orc_render
+ * draw their lens samples from it, seeded with the value the reference took from std::random_device. */
+static uint32_t g_mt[624]; static int g_mti = 624; static int g_lens_mt = 0;
+void orc_lens_mt19937(int enable, uint32_t seed)
+{
+    g_lens_mt = enable;
+    g_mt[0] = seed;
+    for (int i = 1; i < 624; ++i) g_mt[i] = 1812433253u * (g_mt[i - 1] ^ (g_mt[i - 1] >> 30)) + (uint32_t)i;
+    g_mti = 624;
+}
+static uint32_t mt_next(void)
+{
+    if (g_mti >= 624) {
+        for (int k = 0; k < 624; ++k) {
+            uint32_t y = (g_mt[k] & 0x80000000u) | (g_mt[(k + 1) % 624] & 0x7fffffffu);
+            g_mt[k] = g_mt[(k + 397) % 624] ^ (y >> 1) ^ ((y & 1u) ? 0x9908b0dfu : 0u);
+        }
+        g_mti = 0;
+    }
+    uint32_t y = g_mt[g_mti++];
+    y ^= y >> 11; y ^= (y << 7) & 0x9d2c5680u; y ^= (y << 15) & 0xefc60000u; y ^= y >> 18;
+    return y;
+}
+float orc_lens_uniform(void)
+{
+    float r = (float)mt_next() / 4294967296.0f;
+    return r >= 1.0f ? nextafterf(1.0f, 0.0f) : r;
+}
+
 /* ------------------------------------------------------------------ pixel loop (main.cpp:118-141) */
 uint64_t orc_render(const orc_scene *s, const orc_camera *cam, int nx, int ny, int ns,
                     orc_usrc *u, int j0, int j1, float *rgb_mean, int *irgb)
@@ -266,8 +299,8 @@ uint64_t orc_render(const orc_scene *s, const orc_camera *cam, int nx, int ny, i
                 if (cam->lens_radius > 0.0f) {
                     /* RandomUnitInDisk (camera.cpp:31-44).  Keyed source: try 0 is words 2,3 of group 0
                      * of slot (pixel, sample, 0); try t >= 1 is words 0,1 (t odd) or 2,3 (t even) of
-                     * group (t + 1) / 2.  Other sources: a private splitmix stream, because the
-                     * reference's lens generator is seeded from std::random_device (unpinned). */
+                     * group (t + 1) / 2.  Other sources: the reference's own std::mt19937 stream when
+                     * orc_lens_mt19937 has given its seed, else a private splitmix stream. */
                     uint32_t t = 0;
                     do {
                         float a, b;
@@ -275,6 +308,9 @@ uint64_t orc_render(const orc_scene *s, const orc_camera *cam, int nx, int ny, i
                             int hi = (t == 0) || ((t & 1u) == 0);
                             uint32_t grp = (t + 1u) >> 1;
                             a = orc_usrc_word(u, grp, hi ? 2 : 0); b = orc_usrc_word(u, grp, hi ? 3 : 1); ++t;
+                        } else if (g_lens_mt) {
+                            /* Vec3(dis(gen), dis(gen), 0.0f): the pinned build evaluates the second argument first */
+                            b = orc_lens_uniform(); a = orc_lens_uniform();
                         } else {
                             uint64_t z = (lens_state += 0x9E3779B97F4A7C15ull);
                             z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull; z = (z ^ (z >> 27)) * 0x94D049BB133111EBull; z ^= z >> 31;

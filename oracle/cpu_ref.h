@@ -58,6 +58,11 @@ void orc_quantise(const float mean_rgb[3], int out_rgb[3]);
 uint64_t orc_render(const orc_scene *s, const orc_camera *cam, int nx, int ny, int ns,
                     orc_usrc *u, int j0, int j1, float *rgb_mean, int *irgb);
 
+/* Lens samples of the non-keyed sources from the reference's generator, std::mt19937(seed) read through
+ * std::uniform_real_distribution<float>(0, 1) (camera.cpp:33-35); orc_lens_uniform is one such draw. */
+void orc_lens_mt19937(int enable, uint32_t seed);
+float orc_lens_uniform(void);
+
 /* RandomScene() of main.cpp:41-83 drawing from `u`; arrays must hold 501 entries. Returns count. */
 int orc_random_scene(orc_usrc *u, float *cx, float *cy, float *cz, float *radius, int *type,
                      float *ar, float *ag, float *ab, float *param);

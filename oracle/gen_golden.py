@@ -3,7 +3,8 @@
 
     make -C oracle && python oracle/gen_golden.py
 
-Unit vectors come straight from `ref_harness units|scene|paths`.  Images are rendered by the
+Unit vectors come straight from `ref_harness units|scene|paths|dof`; `ref_harness mainppm` runs the reference's
+unmodified main() once and its output.ppm is stored gzipped.  Images are rendered by the
 reference's own Color()/Camera/Sphere code in row bands (one process per band) and stored as
 float32 .npy (linear mean RGB, rows top to bottom).  Two kinds:
   * keyed ("philox"): every uniform comes from the Philox stream keyed on (pixel, sample, bounce);
@@ -11,6 +12,7 @@ float32 .npy (linear mean RGB, rows top to bottom).  Two kinds:
   * libc: the loop exactly as main.cpp runs it (rand() stream, unseedable lens generator); high
     sample counts, used for the statistical image test.
 """
+import gzip
 import json
 import os
 import subprocess
@@ -60,6 +62,15 @@ def main():
         subprocess.run([H, "scene", os.path.join(G, "scene_final.txt")], check=True)
         subprocess.run([H, "units", G], check=True)
         subprocess.run([H, "paths", os.path.join(G, "color_paths.txt"), "400"], check=True)
+        # Camera::GetRay with the lens in use (std::random_device pinned by the harness), and the file the reference's own
+        # main() writes: 400x300, 5 samples, about 20 s on one core
+        subprocess.run([H, "dof", os.path.join(G, "camera_dof.txt")], check=True)
+        with tempfile.TemporaryDirectory() as d:
+            subprocess.run([H, "mainppm", d], check=True)
+            with open(os.path.join(d, "output.ppm"), "rb") as f:
+                text = f.read()
+        with open(os.path.join(G, "reference_main_output_400x300x5.ppm.gz"), "wb") as f:
+            f.write(gzip.compress(text, 9, mtime=0))
     subprocess.run([H, "tiles", os.path.join(G, "tiles.txt")], check=True)
     with open(os.path.join(G, "stats_report.txt"), "w") as f:
         f.write(subprocess.run([H, "stats"], check=True, capture_output=True, text=True).stdout)

@@ -16,6 +16,7 @@
 #include <string>
 #include <vector>
 #include <random>
+#include <unistd.h>
 
 #define main rt_reference_main
 #include "main.cpp"
@@ -56,6 +57,17 @@ extern "C" int rand(void) noexcept
     if (g_logging) g_log.push_back(v);
     return v;
 }
+
+// ---------------------------------------------------------------- std::random_device interposition
+// Camera::RandomUnitInDisk (camera.cpp:31-44) seeds a thread_local std::mt19937 from std::random_device, so the
+// reference's lens samples differ from run to run.  The three out-of-line members of libstdc++'s random_device are
+// defined here (the executable's definitions take precedence over the shared library's, as with rand()), so the
+// one value the reference draws from it is g_lens_seed and its lens stream becomes a function of that number.
+// Nothing of the reference is changed: its own mt19937 / uniform_real_distribution<float> code still runs.
+static uint32_t g_lens_seed = 20240607u;
+void std::random_device::_M_init(const std::string&) {}
+void std::random_device::_M_fini() {}
+std::random_device::result_type std::random_device::_M_getval() { return g_lens_seed; }
 
 static void philox_slot(uint32_t px, uint32_t smp, uint32_t bounce) { g_px = px; g_smp = smp; g_bounce = bounce; g_draw = 0; }
 static float philox_word(uint32_t px, uint32_t smp, uint32_t bounce, uint32_t group, int w)
@@ -268,6 +280,56 @@ static void gen_camera(const char* path)
     fclose(f);
 }
 
+// Camera::GetRay with the lens in use (camera.cpp:31-53), called on the reference's own Camera objects.  The disk
+// sample each call used is recovered exactly: a second std::mt19937 seeded with the same value runs beside the
+// reference's thread_local one through the same rejection loop, and of the two ways its two draws can be assigned
+// to (x, y) -- the language leaves the order of the two dis(gen) arguments open -- the one that reproduces the
+// returned origin bit for bit is written out.  Must be the first user of GetRay in its process.
+static void gen_camera_dof(const char* path)
+{
+    FILE* f = fopen(path, "w"); Lcg g(67);
+    std::mt19937 mirror(g_lens_seed);
+    std::uniform_real_distribution<float> dis(0.0f, 1.0f);
+    struct Cfg { Vec3 from, at, up; float vfov, aspect, ap, focus; };
+    std::vector<Cfg> cfgs = {
+        { Vec3(13, 2, 3), Vec3(0, 0, 0), Vec3(0, 1, 0), 20.0f, 1200.0f / 800.0f, 0.1f, 10.0f },
+        { Vec3(13, 2, 3), Vec3(0, 0, 0), Vec3(0, 1, 0), 20.0f, 3840.0f / 2160.0f, 0.1f, 10.0f },
+        { Vec3(13, 2, 3), Vec3(0, 0, 0), Vec3(0, 1, 0), 20.0f, 400.0f / 300.0f, 0.1f, 10.0f },
+        { Vec3(-2, 2, 1), Vec3(0, 0, -1), Vec3(0, 1, 0), 35.0f, 2.0f, 2.0f, 3.4f },
+        { Vec3(3, 3, 2), Vec3(0, 0, -1), Vec3(0.2f, 1, 0.1f), 55.0f, 1.0f, 0.5f, 5.2f },
+    };
+    std::vector<std::string> rows; int first_is_x = 0, first_is_y = 0;
+    for (const Cfg& c : cfgs) {
+        Camera cam(c.from, c.at, c.up, c.vfov, c.aspect, c.ap, c.focus);
+        for (int k = 0; k < 40; ++k) {
+            float s = g.uni(), t = g.uni();
+            Ray r = cam.GetRay(s, t);
+            float a, b; int tries = 0;
+            do { a = dis(mirror); b = dis(mirror); ++tries; } while ((2.0f * a - 1.0f) * (2.0f * a - 1.0f) + (2.0f * b - 1.0f) * (2.0f * b - 1.0f) + 0.0f >= 1.0f);
+            float disk[2] = { 0, 0 }; bool found = false;
+            for (int order = 0; order < 2 && !found; ++order) {
+                const float x = 2.0f * (order == 0 ? a : b) - 1.0f, y = 2.0f * (order == 0 ? b : a) - 1.0f;
+                Vec3 rd = cam.m_fLensRadius * Vec3(x, y, 0.0f);
+                Vec3 o = cam.m_oOrigin + (cam.m_oU * rd.GetX() + cam.m_oV * rd.GetY());
+                if (memcmp(o.m_fAxis, r.m_oOrigin.m_fAxis, sizeof o.m_fAxis) == 0) { disk[0] = x; disk[1] = y; found = true; (order == 0 ? first_is_x : first_is_y) += (a != b); }
+            }
+            if (!found) { fprintf(stderr, "dof: lens sample not recovered (config %zu, ray %d)\n", (size_t)(&c - &cfgs[0]), k); abort(); }
+            char buf[1024]; int n = 0;
+            auto put3 = [&](const Vec3& v) { n += snprintf(buf + n, sizeof buf - n, " %.9g %.9g %.9g", v.m_fAxis[0], v.m_fAxis[1], v.m_fAxis[2]); };
+            n += snprintf(buf + n, sizeof buf - n, "ray"); put3(c.from); put3(c.at); put3(c.up);
+            n += snprintf(buf + n, sizeof buf - n, " %.9g %.9g %.9g %.9g %.9g %.9g %.9g %.9g %d", c.vfov, c.aspect, c.ap, c.focus, s, t, disk[0], disk[1], tries);
+            put3(r.m_oOrigin); put3(r.m_oDirection);
+            rows.push_back(buf);
+        }
+    }
+    if (first_is_x != 0 && first_is_y != 0) { fprintf(stderr, "dof: inconsistent draw order\n"); abort(); }
+    fprintf(f, "# Camera::GetRay of the reference with std::random_device pinned to %u (camera.cpp:31-53)\n", g_lens_seed);
+    fprintf(f, "# first draw of a lens try is %s\n", first_is_y ? "y" : "x");
+    fprintf(f, "# ray: from(3) at(3) up(3) vfov aspect aperture focus s t disk_x disk_y tries | ray_o(3) ray_d(3)\n");
+    for (const std::string& r : rows) fprintf(f, "%s\n", r.c_str());
+    fclose(f);
+}
+
 // Whole-path vectors: Color() on the final scene for camera rays (aperture 0 => no lens RNG),
 // with every rand() draw logged so a replay reproduces the path exactly.
 static void gen_paths(const char* path, int n)
@@ -360,7 +422,7 @@ extern "C" uint64_t ref_render_rows(const char* scene, int nx, int ny, int ns, u
 #ifndef REF_HARNESS_NO_MAIN
 int main(int argc, char** argv)
 {
-    if (argc < 2) { fprintf(stderr, "usage: ref_harness scene|units|paths|render ...\n"); return 2; }
+    if (argc < 2) { fprintf(stderr, "usage: ref_harness scene|units|dof|mainppm|tiles|stats|paths|render ...\n"); return 2; }
     std::string cmd = argv[1];
     if (cmd == "scene") { long draws = 0; Hittable* w = final_scene(&draws); write_scene(argv[2], w, draws); return 0; }
     if (cmd == "units") {
@@ -388,6 +450,16 @@ int main(int argc, char** argv)
         RenderStats st; st.rays_traced = 98765432; st.intersection_tests = 61234567; st.material_evaluations = 51234567; st.total_time_ms = 1234.5678;
         st.print_stats();
         return 0;
+    }
+    if (cmd == "dof") { gen_camera_dof(argv[2]); return 0; }
+    if (cmd == "mainppm") {
+        // The reference's own main() (main.cpp:85-149), unmodified, run once in directory argv[2]: 400x300, 5 samples, glibc's
+        // default rand() stream, lens generator seeded with g_lens_seed.  output.ppm is created empty beforehand because
+        // main.cpp:91-93 opens it with std::fstream's default mode, which does not create a missing file.
+        if (chdir(argv[2]) != 0) { perror("chdir"); return 2; }
+        { FILE* f = fopen("output.ppm", "w"); if (!f) { perror("output.ppm"); return 2; } fclose(f); }
+        g_mode = RAND_LIBC;
+        return rt_reference_main(0, nullptr);
     }
     if (cmd == "paths") { gen_paths(argv[2], atoi(argv[3])); return 0; }
     if (cmd == "render") {

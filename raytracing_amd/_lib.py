@@ -15,7 +15,7 @@ LAMBERTIAN, METAL, DIELECTRIC = 0, 1, 2
 EXPORTS = ["rt_device_count", "rt_create", "rt_destroy", "rt_last_error", "rt_upload_scene", "rt_set_camera",
            "rt_owned_rows", "rt_owned_pixels", "rt_render_device", "rt_render_stats", "rt_render_counters", "rt_render",
            "rt_scene_grid", "rt_build_hierarchy", "rt_format_ppm", "rt_write_ppm", "rt_write_ppm_binary", "rt_encode_ppm_device", "rt_write_ppm_device", "rt_test_sphere_hit", "rt_test_scatter", "rt_test_get_ray",
-           "rt_test_philox"]
+           "rt_test_helpers", "rt_test_philox"]
 
 
 class RtError(RuntimeError):
@@ -105,6 +105,7 @@ def load_library():
     L.rt_test_sphere_hit.argtypes = [vp, C.c_int, fp, fp, fp, fp, fp, fp, ip, fp, fp, fp]
     L.rt_test_scatter.argtypes = [vp, C.c_int, ip, fp, fp, fp, fp, fp, fp, ip, C.c_int, ip, fp, fp, fp, ip]
     L.rt_test_get_ray.argtypes = [vp, C.c_int, C.POINTER(CameraPod), fp, fp, fp, fp, fp]
+    L.rt_test_helpers.argtypes = [vp, C.c_int, fp, fp, fp, fp, fp, fp, ip, fp, fp]
     L.rt_test_philox.argtypes = [vp, C.c_int, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]
     _lib = L
     return L
@@ -288,6 +289,16 @@ class Renderer:
         ro, rd = np.zeros(3 * n, np.float32), np.zeros(3 * n, np.float32)
         self._check(self._L.rt_test_get_ray(self._ctx, n, C.byref(pod), _fp(s_), _fp(t_), _fp(d_), _fp(ro), _fp(rd)))
         return ro.reshape(n, 3), rd.reshape(n, 3)
+
+    def test_helpers(self, v, normal, ni_over_nt, cosine, ref_idx):
+        """Reflect / Refract / Schlick on arrays -> (reflected[n,3], refract_ok[n], refracted[n,3], schlick[n])."""
+        n = len(cosine)
+        v_, n_ = _f32(v).reshape(-1), _f32(normal).reshape(-1)
+        a, b, c = _f32(ni_over_nt), _f32(cosine), _f32(ref_idx)
+        refl, refr, sch = np.zeros(3 * n, np.float32), np.zeros(3 * n, np.float32), np.zeros(n, np.float32)
+        ok = np.zeros(n, np.int32)
+        self._check(self._L.rt_test_helpers(self._ctx, n, _fp(v_), _fp(n_), _fp(a), _fp(b), _fp(c), _fp(refl), _ip(ok), _fp(refr), _fp(sch)))
+        return refl.reshape(n, 3), ok, refr.reshape(n, 3), sch
 
     def test_philox(self, ctr, key):
         c = np.ascontiguousarray(ctr, dtype=np.uint32).reshape(-1)

@@ -41,6 +41,21 @@ __global__ void k_test_get_ray(int n, const CameraD cam, const float* s, const f
     rd[3 * e] = r.d.x; rd[3 * e + 1] = r.d.y; rd[3 * e + 2] = r.d.z;
 }
 
+__global__ void k_test_helpers(int n, const float* v, const float* nrm, const float* nint, const float* cosine, const float* ref,
+                               float* refl, int32_t* ok, float* refr, float* sch)
+{
+    const int e = blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= n) return;
+    const V3 vin = mk(v[3 * e], v[3 * e + 1], v[3 * e + 2]), nn = mk(nrm[3 * e], nrm[3 * e + 1], nrm[3 * e + 2]);
+    const V3 r = reflect(vin, nn);
+    refl[3 * e] = r.x; refl[3 * e + 1] = r.y; refl[3 * e + 2] = r.z;
+    V3 t = mk(0, 0, 0);
+    const bool good = refract(vin, nn, nint[e], t);
+    ok[e] = good ? 1 : 0;
+    refr[3 * e] = good ? t.x : 0; refr[3 * e + 1] = good ? t.y : 0; refr[3 * e + 2] = good ? t.z : 0;
+    sch[e] = schlick(cosine[e], ref[e]);
+}
+
 __global__ void k_test_philox(int n, const uint32_t* ctr, uint32_t k0, uint32_t k1, uint32_t* out)
 {
     const int e = blockIdx.x * blockDim.x + threadIdx.x;
@@ -103,6 +118,23 @@ int rt_test_get_ray(rt_context* ctx, int n, const rt_camera_pod* cam, const floa
     hipLaunchKernelGGL(k_test_get_ray, dim3((n + 63) / 64), dim3(64), 0, 0, n, to_device(*cam), ds.as<float>(), dt.as<float>(), dd.as<float>(), o.as<float>(), d.as<float>());
     HIP_TRY(ctx, hipGetLastError()); HIP_TRY(ctx, hipDeviceSynchronize());
     HIP_TRY(ctx, o.down(ray_o, f3)); HIP_TRY(ctx, d.down(ray_d, f3));
+    return RT_OK;
+}
+
+int rt_test_helpers(rt_context* ctx, int n, const float* v, const float* normal, const float* ni_over_nt, const float* cosine,
+                    const float* ref_idx, float* reflected, int32_t* refract_ok, float* refracted, float* schlick_out)
+{
+    if (!ctx) return fail(nullptr, RT_ERR_INVALID, "rt_test_helpers: null context");
+    if (n <= 0 || !v || !normal || !ni_over_nt || !cosine || !ref_idx || !reflected || !refract_ok || !refracted || !schlick_out) return fail(ctx, RT_ERR_INVALID, "rt_test_helpers: bad argument");
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    DevBuf dv, dn, di, dc, dr, orf, ook, ort, os;
+    const size_t f3 = sizeof(float) * 3 * n, f1 = sizeof(float) * n;
+    HIP_TRY(ctx, dv.up(v, f3)); HIP_TRY(ctx, dn.up(normal, f3)); HIP_TRY(ctx, di.up(ni_over_nt, f1)); HIP_TRY(ctx, dc.up(cosine, f1)); HIP_TRY(ctx, dr.up(ref_idx, f1));
+    HIP_TRY(ctx, orf.up(nullptr, f3)); HIP_TRY(ctx, ook.up(nullptr, sizeof(int32_t) * n)); HIP_TRY(ctx, ort.up(nullptr, f3)); HIP_TRY(ctx, os.up(nullptr, f1));
+    hipLaunchKernelGGL(k_test_helpers, dim3((n + 63) / 64), dim3(64), 0, 0, n, dv.as<float>(), dn.as<float>(), di.as<float>(), dc.as<float>(), dr.as<float>(),
+                       orf.as<float>(), ook.as<int32_t>(), ort.as<float>(), os.as<float>());
+    HIP_TRY(ctx, hipGetLastError()); HIP_TRY(ctx, hipDeviceSynchronize());
+    HIP_TRY(ctx, orf.down(reflected, f3)); HIP_TRY(ctx, ook.down(refract_ok, sizeof(int32_t) * n)); HIP_TRY(ctx, ort.down(refracted, f3)); HIP_TRY(ctx, os.down(schlick_out, f1));
     return RT_OK;
 }
 

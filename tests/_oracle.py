@@ -93,6 +93,9 @@ def _proto(L):
     L.orc_random_scene.argtypes = [C.POINTER(USrc)] + [C.POINTER(C.c_float)] * 4 + [C.POINTER(C.c_int)] + [C.POINTER(C.c_float)] * 4
     L.orc_quantise.argtypes = [C.POINTER(C.c_float), C.POINTER(C.c_int)]
     L.orc_counters_reset.argtypes = []
+    L.orc_lens_mt19937.argtypes = [C.c_int, C.c_uint32]
+    L.orc_lens_uniform.restype = C.c_float
+    L.orc_lens_uniform.argtypes = []
     L.orc_counters_get.argtypes = [C.POINTER(C.c_uint64)]
 
 

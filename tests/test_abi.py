@@ -144,3 +144,15 @@ def test_sphere_hierarchy_invariants():
     ground = R.final_scene_table()
     _, _, big, _ = build_hierarchy(ground)
     assert 0 in big                      # the r = 1000 ground sphere is tested directly, not boxed
+
+
+def test_format_ppm_reproduces_the_file_the_reference_wrote():
+    """output.ppm written by the reference's own main() (main.cpp:91-97, 143-147; generated once by
+    `oracle/_ref/ref_harness mainppm`): rt_format_ppm of its integers gives back the file byte for byte."""
+    import gzip
+    with gzip.open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "reference_main_output_400x300x5.ppm.gz"), "rb") as f:
+        text = f.read()
+    tok = text.split()
+    assert tok[:4] == [b"P3", b"400", b"300", b"255"]
+    img = np.array(tok[4:], dtype=np.int32).reshape(300, 400, 3)
+    assert R.format_ppm(img) == text

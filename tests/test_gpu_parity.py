@@ -102,20 +102,37 @@ def test_get_ray_vs_reference_vectors(rt):
             continue
         v = [np.float32(float(x)) for x in r[1:]]
         if v[11] != 0.0:
-            continue    # aperture > 0 rows carry the reference's unseedable lens sample; covered by the oracle test
+            continue    # rows with the lens in use are in camera_dof.txt, which also holds the disk sample of each
         cam = R.make_camera(v[0:3], v[3:6], v[6:9], v[9], v[10], v[11], v[12])
         ro, rd = rt.test_get_ray(cam, [v[13]], [v[14]], [[0.0, 0.0]])
         assert same(ro[0], v[15:18]) and same(rd[0], v[18:21])
-    # defocus disk: against the oracle's restatement of camera.cpp:46-53
-    cam = R.final_camera(1200, 800)
-    ocam = O.final_camera(1200, 800)
-    rng = np.random.default_rng(3)
-    s, t = rng.random(64, dtype=np.float32), rng.random(64, dtype=np.float32)
-    disk = (rng.random((64, 2), dtype=np.float32) * 1.4 - 0.7).astype(np.float32)
-    ro, rd = rt.test_get_ray(cam, s, t, disk)
-    for e in range(64):
-        w = O.lib().orc_camera_get_ray(C.byref(ocam), s[e], t[e], disk[e, 0], disk[e, 1])
-        assert same(ro[e], w.o.tup()) and same(rd[e], w.d.tup())
+    # defocus disk (camera.cpp:31-53): rays returned by the reference's own Camera::GetRay with std::random_device pinned,
+    # each with the unit-disk sample its lens generator drew -- bit for bit
+    rows = [[np.float32(float(x)) for x in r[1:]] for r in _rows("camera_dof.txt")]
+    assert len(rows) >= 200
+    by_cam = {}
+    for v in rows:
+        by_cam.setdefault(tuple(v[0:13]), []).append(v)
+    for key, group in by_cam.items():
+        cam = R.make_camera(key[0:3], key[3:6], key[6:9], key[9], key[10], key[11], key[12])
+        g = np.array(group, dtype=np.float32)
+        ro, rd = rt.test_get_ray(cam, g[:, 13], g[:, 14], g[:, 15:17])
+        assert same(ro, g[:, 18:21]) and same(rd, g[:, 21:24])
+        assert not same(ro, np.broadcast_to(np.array(key[0:3], np.float32), ro.shape))     # the lens offset is really there
+
+
+def test_reflect_refract_schlick_vs_reference_vectors(rt):
+    """material.h:7-38 through the GPU's own device functions.  Reflect and Refract are the reference's float operations
+    in the reference's order; Schlick's pow(1 - cosine, 5), a libm call in double in the reference, is three double products
+    on the GPU: the number of vectors on which the narrowed float differs is reported and has to be zero here."""
+    t = np.array([[np.float32(float(x)) for x in r] for r in _rows("helpers.txt")], dtype=np.float32)
+    refl, ok, refr, sch = rt.test_helpers(t[:, 0:3], t[:, 3:6], t[:, 6], t[:, 7], t[:, 8])
+    assert same(refl, t[:, 9:12])
+    assert np.array_equal(ok, t[:, 12].astype(np.int32)) and 50 < ok.sum() < len(t)
+    assert same(refr, t[:, 13:16])
+    differing = mismatch(sch, t[:, 16])
+    print(f"Schlick: {differing} of {len(t)} values differ from the reference's libm pow")
+    assert differing == 0
 
 
 def _meta():
@@ -637,6 +654,80 @@ def test_sample_batches_accumulate_in_sample_order(monkeypatch, mode):
         tiny.render(tiny.params(m["nx"], m["ny"], m["ns"], seed=m["seed"], mode=mode))
     assert e.value.code == -5
     r.close(); tiny.close()
+
+
+def _ref_band():
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "oracle"))
+    import ref_band
+    return ref_band
+
+
+def test_config4_rows_match_oracle_and_reference_build(rt):
+    """3840x2160 (the multi-GPU configuration; camera of main.cpp:111-116 at 16:9): two rows at three heights, 2 samples,
+    every kernel organisation, against the CPU oracle and -- where the pinned build of the reference is present -- against
+    the reference's own code on the keyed stream."""
+    W, H, S, seed = 3840, 2160, 2, 17
+    scene = O.SceneArrays.from_table(O.load_scene_table())
+    ocam = O.final_camera(W, H)
+    rt.upload_scene(R.final_scene_table())
+    rt.set_camera(R.final_camera(W, H))
+    rb = _ref_band()
+    for y0 in (300, 1100, 1800):                 # sky, sphere field, foreground (rows counted from the top)
+        want, wq, wrays = O.render(scene, ocam, W, H, S, O.usrc_philox(seed), H - (y0 + 2), H - y0)
+        if rb.exact_available():
+            ref_img, ref_rays = rb.keyed_band_exact(W, H, S, H - (y0 + 2), 2, seed)
+            assert ref_rays == wrays and mismatch(ref_img, want) == 0
+        for mode in (R.MODE_MEGAKERNEL, R.MODE_WAVEFRONT, R.MODE_PIXEL, R.MODE_BVH):
+            p = rt.params(W, H, S, seed=seed, band_rows=2, band_first=y0 // 2, band_step=100000, mode=mode)
+            rgb, irgb, rays, _ = rt.render(p)
+            assert rgb.shape == (2, W, 3)
+            assert rays == wrays and mismatch(rgb, want) == 0 and np.array_equal(irgb, wq), (y0, mode)
+
+
+def test_config4_full_render_equals_its_eight_way_partition(rt):
+    """3840x2160 at 1024 samples per pixel on one GPU (8.5e9 samples, several sample batches with a running sum) against
+    the same image rendered as the eight interleaved one-row-band shares the 8-GPU partition gives its ranks: same ray
+    count, same integer image."""
+    import torch
+    W, H, S, seed = 3840, 2160, 1024, 3
+    rt.upload_scene(R.final_scene_table())
+    rt.set_camera(R.final_camera(W, H))
+    whole = torch.zeros((H, W, 3), dtype=torch.int32, device="cuda")
+    rt.render_device(rt.params(W, H, S, seed=seed), 0, whole.data_ptr())
+    rays_whole, ms = rt.stats()
+    assert 2.4 < rays_whole / (W * H * S) < 3.0
+    parts = torch.zeros((H, W, 3), dtype=torch.int32, device="cuda")
+    total = 0
+    for rank in range(8):
+        p = rt.params(W, H, S, seed=seed, band_rows=1, band_first=rank, band_step=8)
+        rows = rt.owned_rows(p)
+        assert rows == H // 8
+        share = torch.zeros((rows, W, 3), dtype=torch.int32, device="cuda")
+        rt.render_device(p, 0, share.data_ptr())
+        r, _ = rt.stats()
+        total += r
+        parts[rank::8] = share
+    assert total == rays_whole
+    assert torch.equal(parts, whole)
+    assert int(whole.min()) >= 0 and int(whole.max()) <= 255
+    print(f"config 4 on one GPU: {ms:.0f} ms, {rays_whole / ms / 1e3:.0f} Mrays/s, checksum {int(whole.to(torch.int64).sum())}")
+
+
+def test_ppm_text_of_the_reference_image_on_the_gpu(rt):
+    """The integers of the output.ppm that the reference's own main() wrote (main.cpp:91-97, 143-147), encoded on the GPU:
+    the text has to be that file, byte for byte."""
+    import gzip
+    import torch
+    with gzip.open(os.path.join(G, "reference_main_output_400x300x5.ppm.gz"), "rb") as f:
+        text = f.read()
+    img = np.array(text.split()[4:], dtype=np.int32).reshape(300, 400, 3)
+    d_img = torch.from_numpy(img).cuda()
+    need = rt.encode_ppm_device(d_img.data_ptr(), 400, 300)
+    assert need == len(text)
+    d_text = torch.zeros(need, dtype=torch.uint8, device="cuda")
+    rt.encode_ppm_device(d_img.data_ptr(), 400, 300, d_text.data_ptr(), need)
+    torch.cuda.synchronize()
+    assert d_text.cpu().numpy().tobytes() == text
 
 
 def test_device_pointer_form_on_a_side_stream(rt):

@@ -226,3 +226,67 @@ def test_band_rendering_is_consistent():
     lo, _, r0 = O.render(scene, cam, 32, 18, 4, O.usrc_philox(5), 0, 7)
     hi, _, r1 = O.render(scene, cam, 32, 18, 4, O.usrc_philox(5), 7, 18)
     assert same(np.concatenate([hi, lo], axis=0), whole) and r0 + r1 == rays
+
+
+def test_get_ray_with_the_lens_matches_reference():
+    """Camera::GetRay with aperture > 0 (camera.cpp:31-53): rays returned by the reference's own Camera objects with
+    std::random_device pinned (oracle/ref_harness.cpp), each with the unit-disk sample its lens generator drew."""
+    rows = _rows("camera_dof.txt")
+    assert len(rows) >= 200
+    for r in rows:
+        v = [f32(x) for x in r[1:]]
+        cam = O.make_camera(v[0:3], v[3:6], v[6:9], v[9], v[10], v[11], v[12])
+        assert cam.lens_radius > 0.0
+        ray = O.lib().orc_camera_get_ray(C.byref(cam), v[13], v[14], v[15], v[16])
+        assert same([*ray.o.tup(), *ray.d.tup()], v[18:24])
+
+
+def test_lens_generator_matches_reference():
+    """The oracle's std::mt19937 / uniform_real_distribution<float> restatement replays the disk samples the reference's
+    generator produced: same accepted samples after the same number of rejected tries."""
+    O.lib().orc_lens_mt19937(1, 20240607)
+    try:
+        for r in _rows("camera_dof.txt"):
+            want_x, want_y, tries = f32(r[16]), f32(r[17]), int(r[18])
+            for k in range(tries):
+                y = np.float32(2.0) * np.float32(O.lib().orc_lens_uniform()) - np.float32(1.0)      # the second argument draws first
+                x = np.float32(2.0) * np.float32(O.lib().orc_lens_uniform()) - np.float32(1.0)
+                inside = np.float32(np.float32(x * x) + np.float32(y * y)) < np.float32(1.0)
+                assert inside == (k == tries - 1)
+            assert same([x, y], [want_x, want_y])
+    finally:
+        O.lib().orc_lens_mt19937(0, 0)
+
+
+def reference_main_ppm():
+    import gzip
+    with gzip.open(os.path.join(G, "reference_main_output_400x300x5.ppm.gz"), "rb") as f:
+        return f.read()
+
+
+def test_whole_main_output_ppm_is_reproduced():
+    """output.ppm as the reference's unmodified main() wrote it (main.cpp:85-149: 400x300, 5 samples, glibc's default
+    rand() stream, lens generator seeded with the pinned std::random_device value): the oracle replays the same
+    sequence -- RandomScene(), camera, pixel loop with depth of field, gamma, quantisation -- and must arrive at every
+    integer of the file."""
+    import ctypes.util
+    text = reference_main_ppm()
+    assert text.startswith(b"P3\n400 300\n255\n")
+    want = np.array(text.split()[4:], dtype=np.int64).reshape(300, 400, 3)
+    libc = C.CDLL(ctypes.util.find_library("c"))
+    libc.srandom(1)
+    u = O.usrc_libc()
+    f = lambda: np.zeros(501, dtype=np.float32)
+    cx, cy, cz, rad, ar, ag, ab, par = f(), f(), f(), f(), f(), f(), f(), f()
+    typ = np.zeros(501, dtype=np.int32)
+    fp = lambda a: a.ctypes.data_as(C.POINTER(C.c_float))
+    n = O.lib().orc_random_scene(C.byref(u), fp(cx), fp(cy), fp(cz), fp(rad), typ.ctypes.data_as(C.POINTER(C.c_int)),
+                                 fp(ar), fp(ag), fp(ab), fp(par))
+    scene = O.SceneArrays(cx[:n], cy[:n], cz[:n], rad[:n], typ[:n], ar[:n], ag[:n], ab[:n], par[:n])
+    cam = O.final_camera(400, 300)
+    O.lib().orc_lens_mt19937(1, 20240607)
+    try:
+        _, irgb, _ = O.render(scene, cam, 400, 300, 5, u)
+    finally:
+        O.lib().orc_lens_mt19937(0, 0)
+    assert np.array_equal(irgb.astype(np.int64), want)
