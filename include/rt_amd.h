@@ -167,6 +167,16 @@ int rt_write_ppm_binary(const char *path, const int32_t *irgb, int width, int he
  * length pass on `stream`; the write pass is enqueued on it and not waited for. */
 int rt_encode_ppm_device(rt_context *ctx, const int32_t *d_irgb, int width, int height, char *d_text,
                          int64_t cap, int64_t *bytes, void *stream);
+/* rt_encode_ppm_device for callers that cannot allocate device memory (code under HIP graph capture, tight serving loops,
+ * harnesses that forbid hipMalloc).  It has no counterpart in the reference.  The per-block lengths and offsets live in a
+ * fixed array inside the library instead of allocated memory, which limits the image to RT_PPM_NOALLOC_MAX_PIXELS pixels
+ * (RT_ERR_TOO_LARGE beyond); the call allocates nothing, copies nothing to the host and does not wait: the text length goes
+ * to *d_bytes, an int64 in DEVICE memory, and the text is written only if that length fits `cap` (decided on the GPU;
+ * d_text may be NULL to get the length alone).  All work is enqueued on `stream`.  Every call on one GPU uses the same
+ * array: calls that overlap in time on one GPU (two streams, two contexts) race and must be serialised by the caller. */
+#define RT_PPM_NOALLOC_MAX_PIXELS (16u << 20)
+int rt_encode_ppm_device_noalloc(rt_context *ctx, const int32_t *d_irgb, int width, int height, char *d_text,
+                                 int64_t cap, int64_t *d_bytes, void *stream);
 /* rt_encode_ppm_device into a temporary device buffer, one copy to the host, then the file write. */
 int rt_write_ppm_device(rt_context *ctx, const char *path, const int32_t *d_irgb, int width, int height,
                         void *stream);

@@ -14,7 +14,7 @@ LAMBERTIAN, METAL, DIELECTRIC = 0, 1, 2
 # every symbol include/rt_amd.h declares
 EXPORTS = ["rt_device_count", "rt_create", "rt_destroy", "rt_last_error", "rt_upload_scene", "rt_set_camera",
            "rt_owned_rows", "rt_owned_pixels", "rt_render_device", "rt_render_stats", "rt_render_counters", "rt_render",
-           "rt_scene_grid", "rt_build_hierarchy", "rt_format_ppm", "rt_write_ppm", "rt_write_ppm_binary", "rt_encode_ppm_device", "rt_write_ppm_device", "rt_test_sphere_hit", "rt_test_scatter", "rt_test_get_ray",
+           "rt_scene_grid", "rt_build_hierarchy", "rt_format_ppm", "rt_write_ppm", "rt_write_ppm_binary", "rt_encode_ppm_device", "rt_encode_ppm_device_noalloc", "rt_write_ppm_device", "rt_test_sphere_hit", "rt_test_scatter", "rt_test_get_ray",
            "rt_test_helpers", "rt_test_philox"]
 
 
@@ -101,6 +101,7 @@ def load_library():
     L.rt_write_ppm.argtypes = [C.c_char_p, ip, C.c_int, C.c_int]
     L.rt_write_ppm_binary.argtypes = [C.c_char_p, ip, C.c_int, C.c_int]
     L.rt_encode_ppm_device.argtypes = [vp, vp, C.c_int, C.c_int, vp, C.c_int64, C.POINTER(C.c_int64), vp]
+    L.rt_encode_ppm_device_noalloc.argtypes = [vp, vp, C.c_int, C.c_int, vp, C.c_int64, vp, vp]
     L.rt_write_ppm_device.argtypes = [vp, C.c_char_p, vp, C.c_int, C.c_int, vp]
     L.rt_test_sphere_hit.argtypes = [vp, C.c_int, fp, fp, fp, fp, fp, fp, ip, fp, fp, fp]
     L.rt_test_scatter.argtypes = [vp, C.c_int, ip, fp, fp, fp, fp, fp, fp, ip, C.c_int, ip, fp, fp, fp, ip]
@@ -256,6 +257,11 @@ class Renderer:
         if rc != 0 and not (rc == -5 and not d_text):
             self._check(rc)
         return n.value
+
+    def encode_ppm_device_noalloc(self, d_irgb, width, height, d_text, cap, d_bytes, stream=0):
+        """rt_encode_ppm_device_noalloc: enqueue only; the length arrives in the int64 at device address d_bytes."""
+        self._check(self._L.rt_encode_ppm_device_noalloc(self._ctx, C.c_void_p(d_irgb or None), width, height, C.c_void_p(d_text or None), cap,
+                                                         C.c_void_p(d_bytes or None), C.c_void_p(stream or None)))
 
     def write_ppm_device(self, path, d_irgb, width, height, stream=0):
         self._check(self._L.rt_write_ppm_device(self._ctx, os.fsencode(path), C.c_void_p(d_irgb), width, height, C.c_void_p(stream or None)))

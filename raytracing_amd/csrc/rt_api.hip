@@ -57,6 +57,7 @@ int rt_create(int device_ordinal, rt_context** out)
     if (e == hipSuccess) e = hipEventCreate(&ctx->ev0);
     if (e == hipSuccess) e = hipEventCreate(&ctx->ev1);
     if (e != hipSuccess) { fail(nullptr, RT_ERR_HIP, "rt_create: %s", hipGetErrorString(e)); rt_destroy(ctx); return RT_ERR_HIP; }
+    (void)ppm_static_scratch(ctx);      // a failure here only disables rt_encode_ppm_device_noalloc, which then reports it
     *out = ctx;
     return RT_OK;
 }

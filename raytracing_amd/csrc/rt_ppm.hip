@@ -43,6 +43,8 @@ struct PpmArgs {
     uint32_t* block_len; unsigned long long* block_off;    // [blocks], [blocks + 1]
     uint32_t blocks;
     char* text; int header_len; char header[40];
+    // rt_encode_ppm_device_noalloc only: the length goes to device memory and the write pass itself checks the capacity
+    long long* d_bytes; long long cap; int check_on_device;
 };
 
 __device__ __forceinline__ uint32_t ppm_block_scan(uint32_t mine, uint32_t* s_wave, uint32_t& block_total)
@@ -95,7 +97,7 @@ __global__ void __launch_bounds__(1024) k_ppm_scan(const PpmArgs a)
         if (threadIdx.x == 0) s_carry += total;
         __syncthreads();
     }
-    if (threadIdx.x == 0) a.block_off[a.blocks] = s_carry;
+    if (threadIdx.x == 0) { a.block_off[a.blocks] = s_carry; if (a.d_bytes) *a.d_bytes = (long long)s_carry + a.header_len; }
 }
 
 __global__ void __launch_bounds__(kPpmBlock) k_ppm_write(const PpmArgs a)
@@ -103,6 +105,8 @@ __global__ void __launch_bounds__(kPpmBlock) k_ppm_write(const PpmArgs a)
     // text of the block, placed so that LDS byte k lands on HBM byte (dst rounded down to 4) + k
     __shared__ __attribute__((aligned(16))) char s_text[kPpmPxPerBlock * kPpmMaxLine + 8];
     __shared__ uint32_t s_wave[kPpmBlock / 64];
+    // the same for every thread of the grid: a text that does not fit is not written at all
+    if (a.check_on_device && (long long)a.block_off[a.blocks] + a.header_len > a.cap) return;
     const uint32_t first = (blockIdx.x * (uint32_t)kPpmBlock + threadIdx.x) * (uint32_t)kPpmPxPerThread;
     int32_t v[kPpmPxPerThread][3];
     uint32_t mine = 0;
@@ -253,6 +257,52 @@ int rt_encode_ppm_device(rt_context* ctx, const int32_t* d_irgb, int width, int 
     *bytes = (int64_t)body + a.header_len;
     if (!d_text || cap < *bytes) return fail(ctx, RT_ERR_TOO_LARGE, "rt_encode_ppm_device: the text needs %lld bytes, capacity is %lld", (long long)*bytes, (long long)cap);
     hipLaunchKernelGGL(k_ppm_write, dim3(a.blocks), dim3(kPpmBlock), 0, st, a);
+    HIP_TRY(ctx, hipGetLastError());
+    return RT_OK;
+}
+
+// ---------------------------------------------------------------------------- the same encoder without any allocation
+// Scratch of rt_encode_ppm_device_noalloc: the per-block text lengths and offsets that rt_encode_ppm_device keeps in
+// memory it allocates.  One copy per GPU, at its own address on each, held until the process ends.
+}   // extern "C"
+constexpr uint32_t kPpmStaticBlocks = RT_PPM_NOALLOC_MAX_PIXELS / kPpmPxPerBlock;
+constexpr size_t kPpmStaticOffBytes = ((size_t)kPpmStaticBlocks + 1) * sizeof(unsigned long long);
+static __device__ __align__(256) unsigned char scratch[kPpmStaticOffBytes + (size_t)kPpmStaticBlocks * sizeof(uint32_t)];
+
+// Called by rt_create with the context's device current: the device address of this GPU's copy of `scratch`.  In host code
+// the array's name is only a handle for this look-up; every later use goes through the pointer found here.
+int ppm_static_scratch(rt_context* ctx)
+{
+    void* ptr = nullptr;
+    const hipError_t e = hipGetSymbolAddress(&ptr, HIP_SYMBOL(scratch));
+    if (e != hipSuccess || !ptr) { ctx->d_ppm_static = nullptr; return fail(ctx, RT_ERR_HIP, "hipGetSymbolAddress(scratch) failed: %s", hipGetErrorString(e)); }
+    ctx->d_ppm_static = ptr;
+    return RT_OK;
+}
+extern "C" {
+
+int rt_encode_ppm_device_noalloc(rt_context* ctx, const int32_t* d_irgb, int width, int height, char* d_text, int64_t cap, int64_t* d_bytes, void* stream)
+{
+    if (!ctx) return fail(nullptr, RT_ERR_INVALID, "rt_encode_ppm_device_noalloc: null context");
+    if (!d_irgb || width <= 0 || height <= 0 || !d_bytes || cap < 0) return fail(ctx, RT_ERR_INVALID, "rt_encode_ppm_device_noalloc: bad argument");
+    const uint64_t pixels64 = (uint64_t)width * (uint64_t)height;
+    if (pixels64 > (uint64_t)RT_PPM_NOALLOC_MAX_PIXELS)
+        return fail(ctx, RT_ERR_TOO_LARGE, "rt_encode_ppm_device_noalloc: %llu pixels exceed the %u this entry point is built for; use rt_encode_ppm_device", (unsigned long long)pixels64, (unsigned)RT_PPM_NOALLOC_MAX_PIXELS);
+    if (!ctx->d_ppm_static) return fail(ctx, RT_ERR_HIP, "rt_encode_ppm_device_noalloc: the static scratch of this GPU was not found when the context was created");
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    PpmArgs a{};
+    a.irgb = d_irgb; a.pixels = (uint32_t)pixels64;
+    a.blocks = (a.pixels + kPpmPxPerBlock - 1) / kPpmPxPerBlock;
+    a.header_len = snprintf(a.header, sizeof a.header, "P3\n%d %d\n255\n", width, height);
+    // every word of the scratch that the kernels read is written by this call first (lengths by k_ppm_len, offsets and the
+    // total by k_ppm_scan), so what an earlier call left behind does not matter and nothing has to be cleared
+    a.block_off = static_cast<unsigned long long*>(ctx->d_ppm_static);
+    a.block_len = reinterpret_cast<uint32_t*>(static_cast<char*>(ctx->d_ppm_static) + kPpmStaticOffBytes);
+    a.text = d_text; a.d_bytes = reinterpret_cast<long long*>(d_bytes); a.cap = (long long)cap; a.check_on_device = 1;
+    hipLaunchKernelGGL(k_ppm_len, dim3(a.blocks), dim3(kPpmBlock), 0, st, a);
+    hipLaunchKernelGGL(k_ppm_scan, dim3(1), dim3(1024), 0, st, a);
+    if (d_text && cap > 0) hipLaunchKernelGGL(k_ppm_write, dim3(a.blocks), dim3(kPpmBlock), 0, st, a);
     HIP_TRY(ctx, hipGetLastError());
     return RT_OK;
 }
