@@ -80,3 +80,25 @@ def test_band_layout_covers_every_row_once():
         assert len(set(idx.tolist())) == height
         pad = rdist.max_owned_rows(height, band, world)
         assert all(rdist.owned_row_count(height, band, r, world) <= pad for r in range(world))
+
+
+def test_bench_starts_its_own_ranks():
+    """`python bench.py --gpus 2` with no launcher around it: the script starts two ranks itself (before anything touches a
+    GPU), they gather their interleaved rows over gloo and rank 0 prints the one JSON line.  --dry-run replaces the render
+    kernels by a row pattern, so this runs without a GPU."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--dry-run", "--workload", "c1"],
+                       capture_output=True, text=True, timeout=300, env=env, cwd=root)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1
+    line = json.loads(lines[0])
+    assert line["n_gpus"] == 2 and line["ranks_reported_by_backend"] == 2 and line["assembled_image_ok"] is True
+    # a rank count that disagrees with --gpus is refused
+    env2 = dict(env, WORLD_SIZE="3", RANK="0")
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--dry-run"], capture_output=True, text=True, timeout=120, env=env2, cwd=root)
+    assert r.returncode != 0 and "must agree" in (r.stderr + r.stdout)

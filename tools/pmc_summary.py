@@ -1,0 +1,115 @@
+#!/usr/bin/env python3
+"""Turns the rocprofv3 output of tools/profile_round.sh (gpurun_out/<tag>/) into the files kept under profiles/:
+<tag>_kernel_stats.csv (kernel-trace statistics of the default bench command), <tag>_pmc_k_trace.txt (raw counters of k_trace
+with the derived figures) and <tag>_pmc_k_trace.json (per-ray figures bench.py reads for roofline.traffic and executed_frac).
+
+Units as observed on gfx950: SQ_*_CYCLES / SQ_ACTIVE_INST_* / SQ_WAIT_* count in units of four cycles summed over waves;
+SQ_INSTS_* count wave-instructions; FETCH_SIZE under-reports wide coalesced reads by a factor two (calibrated on k_resolve, whose
+bytes are known); WRITE_SIZE is exact; both in KB.  GRBM_GUI_ACTIVE is summed over the eight XCDs.
+"""
+import collections
+import csv
+import glob
+import json
+import os
+import shutil
+import sys
+
+tag = sys.argv[1] if len(sys.argv) > 1 else "r02"
+root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+src = os.path.join(root, "gpurun_out", tag)
+dst = os.path.join(root, "profiles")
+SIMDS, LANES = 1024, 64
+
+
+def counters(name, kernel="k_trace"):
+    agg = collections.defaultdict(float)
+    launches = collections.Counter()
+    for path in glob.glob(os.path.join(src, f"pmc_{name}", "**", "*counter_collection.csv"), recursive=True):
+        for r in csv.DictReader(open(path)):
+            if kernel in r["Kernel_Name"]:
+                agg[r["Counter_Name"]] += float(r["Counter_Value"])
+                launches[r["Counter_Name"]] += 1
+    return agg, launches
+
+
+bench = json.load(open(os.path.join(src, "bench.json")))
+rays_per_sample = bench["rays_per_sample"]
+samples = 1200 * 800 * 50                      # the counter passes run the bench at 50 samples per pixel, one launch
+rays = samples * rays_per_sample
+c = {}
+for name in "abc":
+    a, _ = counters(name)
+    c.update(a)
+fetch, _ = counters("fetch")
+write, _ = counters("write")
+rfetch, _ = counters("fetch", "k_resolve")
+stats = glob.glob(os.path.join(src, "trace", "**", "*kernel_stats.csv"), recursive=True)
+if stats:
+    shutil.copy(stats[0], os.path.join(dst, f"{tag}_kernel_stats.csv"))
+shutil.copy(os.path.join(src, "bench.json"), os.path.join(dst, f"{tag}_bench_line.json"))
+
+kernel_cycles = c.get("GRBM_GUI_ACTIVE", 0.0) / 8.0                 # shader cycles the launch lasted
+insts = c["SQ_INSTS_VALU"]
+lanes = c["SQ_THREAD_CYCLES_VALU"] / insts                           # mean active lanes per vector instruction
+fma, add, mul, trans = (c.get(k, 0.0) for k in ("SQ_INSTS_VALU_FMA_F32", "SQ_INSTS_VALU_ADD_F32", "SQ_INSTS_VALU_MUL_F32", "SQ_INSTS_VALU_TRANS_F32"))
+# executed FP32 operations per ray, two ways: every FP32 instruction at all 64 lanes (upper bound: what the ALU was occupied
+# for), and scaled by the mean active-lane share of all vector instructions (the filter's FMAs run with every lane of a live
+# ray active, so the truth lies between)
+flop_wave = (2 * fma + add + mul + trans) * LANES
+executed_flop_per_ray_upper = flop_wave / rays
+executed_flop_per_ray_lanes = flop_wave * (lanes / LANES) / rays
+hbm_bytes = (2.0 * fetch.get("FETCH_SIZE", 0.0) + write.get("WRITE_SIZE", 0.0)) * 1024.0
+summary = {
+    "tag": tag, "workload": "1200x800 final scene, 50 spp (one launch of k_trace per counter pass)", "spheres": 487,
+    "rays": rays, "hbm_bytes_per_ray": hbm_bytes / rays,
+    "valu_insts_per_64_rays": insts / (rays / 64), "mean_active_lanes": lanes,
+    "fma_f32_per_64_rays": fma / (rays / 64), "add_f32_per_64_rays": add / (rays / 64), "mul_f32_per_64_rays": mul / (rays / 64),
+    "trans_f32_per_64_rays": trans / (rays / 64), "int32_per_64_rays": c.get("SQ_INSTS_VALU_INT32", 0.0) / (rays / 64),
+    "executed_flop_per_ray": executed_flop_per_ray_upper, "executed_flop_per_ray_active_lanes": executed_flop_per_ray_lanes,
+    "valu_utilization": lanes / LANES,
+    "kernel_cycles": kernel_cycles,
+}
+if kernel_cycles > 0:
+    # VALUBusy as rocprof's gfx9 formula defines it (4 cycles per vector instruction): on this part a plain FP32 instruction holds
+    # the pipe for 2, so the figure can exceed 1; valu_issue_frac prices every instruction at 2 cycles instead (a lower bound of
+    # the share of SIMD cycles with a vector instruction in the pipe)
+    summary["valu_busy_gfx9_formula"] = c["SQ_ACTIVE_INST_VALU"] * 4 / SIMDS / kernel_cycles
+    summary["valu_issue_frac"] = insts * 2 / SIMDS / kernel_cycles
+# kernel-trace of the default bench command: its k_trace launches are the headline workload's (config 3, ~90 ms each) and the
+# 23 short ones of the config-1 line; the statistics file averages over both, so the two groups are separated here
+groups = {"headline": [], "config1": []}
+for path in glob.glob(os.path.join(src, "trace", "**", "*kernel_trace.csv"), recursive=True):
+    for r in csv.DictReader(open(path)):
+        if "k_trace" in r["Kernel_Name"]:
+            ms = (float(r["End_Timestamp"]) - float(r["Start_Timestamp"])) * 1e-6
+            groups["headline" if ms > 20.0 else "config1"].append(ms)
+for g, v in groups.items():
+    if v:
+        summary[f"kernel_trace_{g}_launches"] = len(v)
+        summary[f"kernel_trace_{g}_mean_ms"] = sum(v) / len(v)
+summary["bench_kernel_ms_mean"] = bench.get("kernel_ms_mean")
+with open(os.path.join(dst, f"{tag}_pmc_k_trace.json"), "w") as f:
+    json.dump(summary, f, indent=1)
+with open(os.path.join(dst, f"{tag}_pmc_k_trace.txt"), "w") as f:
+    f.write(f"# k_trace, bench.py --spp 50 --steps 1 (one launch per pass, {rays:.4g} rays); passes a, b, c of tools/profile_round.sh\n")
+    for k, v in sorted(c.items()):
+        f.write(f"{k} {v:.0f}\n")
+    f.write(f"FETCH_SIZE_KB {fetch.get('FETCH_SIZE', 0):.0f}\nWRITE_SIZE_KB {write.get('WRITE_SIZE', 0):.0f}\nk_resolve_FETCH_SIZE_KB {rfetch.get('FETCH_SIZE', 0):.0f} (known bytes: {samples * 12 / 1024:.0f} KB)\n")
+    wc = c["SQ_WAVE_CYCLES"]
+    f.write(f"# per 64 rays: VALU {summary['valu_insts_per_64_rays']:.0f} wave-instructions (FMA_F32 {summary['fma_f32_per_64_rays']:.0f}, ADD_F32 {summary['add_f32_per_64_rays']:.0f}, "
+            f"MUL_F32 {summary['mul_f32_per_64_rays']:.0f}, TRANS_F32 {summary['trans_f32_per_64_rays']:.0f}, INT32 {summary['int32_per_64_rays']:.0f}), "
+            f"SALU {c['SQ_INSTS_SALU'] / (rays / 64):.0f}, SMEM {c['SQ_INSTS_SMEM'] / (rays / 64):.0f}, LDS {c['SQ_INSTS_LDS'] / (rays / 64):.0f}\n")
+    f.write(f"# VALUUtilization (active lanes per vector instruction): {lanes:.1f} / 64 = {lanes / 64:.3f}\n")
+    if kernel_cycles > 0:
+        f.write(f"# kernel duration {kernel_cycles:.4g} shader cycles (GRBM_GUI_ACTIVE / 8 XCDs); VALUBusy by the gfx9 formula (4 cycles per instruction) "
+                f"{summary['valu_busy_gfx9_formula']:.3f}; at 2 cycles per instruction {summary['valu_issue_frac']:.3f} of SIMD cycles\n")
+    f.write(f"# wave time split: active {c['SQ_ACTIVE_INST_ANY'] / wc:.2f} issue-stall {c['SQ_WAIT_INST_ANY'] / wc:.2f} waitcnt {c['SQ_WAIT_ANY'] / wc:.2f}; waves {c['SQ_WAVES']:.0f}\n")
+    f.write(f"# executed FP32 operations per ray: {executed_flop_per_ray_upper:.0f} with all 64 lanes counted, {executed_flop_per_ray_lanes:.0f} scaled by the active-lane share; "
+            f"algorithmic (reference) work per ray: {18 * 487 + 150}\n")
+    f.write(f"# HBM bytes per ray: {summary['hbm_bytes_per_ray']:.1f} (FETCH_SIZE x 2 + WRITE_SIZE)\n")
+    if groups["headline"]:
+        f.write(f"# rocprofv3 --kernel-trace of the default bench command: {len(groups['headline'])} k_trace launches of the headline workload, mean {summary['kernel_trace_headline_mean_ms']:.2f} ms "
+                f"(bench.py's HIP-event figure, which also spans k_resolve: {bench.get('kernel_ms_mean'):.2f} ms); {len(groups['config1'])} launches of the config-1 line, mean "
+                f"{summary.get('kernel_trace_config1_mean_ms', 0):.3f} ms -- the statistics file averages over both groups\n")
+print(json.dumps(summary, indent=1))
