@@ -216,6 +216,9 @@ int rt_render_device(rt_context* ctx, const rt_params* p, float* d_rgb_mean, int
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     hipStream_t st = static_cast<hipStream_t>(stream);
     const int owned = (int)rt_owned_rows(p);
+    // The counters, the sample buffer, the staging rows, the hit stacks and the tile order belong to the context, not to the
+    // call: a render enqueued on another stream than the one before has to start after that one has finished with them.
+    if (ctx->pending && st != ctx->last_stream) HIP_TRY(ctx, hipStreamWaitEvent(st, ctx->ev1, 0));
     HIP_TRY(ctx, hipMemsetAsync(ctx->d_rays, 0, 2 * sizeof(unsigned long long), st));
     HIP_TRY(ctx, hipEventRecord(ctx->ev0, st));
     if (owned > 0) {

@@ -89,20 +89,26 @@ struct Builder {
 inline bool build_bvh(int n, const float* cx, const float* cy, const float* cz, const float* radius, BvhHost* out)
 {
     *out = BvhHost();
-    std::vector<float> mags(n);
-    for (int i = 0; i < n; ++i) mags[i] = std::fabs(radius[i]);
-    std::vector<float> sorted(mags);
-    std::nth_element(sorted.begin(), sorted.begin() + n / 2, sorted.end());
-    const float median = sorted[n / 2];
+    // A sphere whose centre or radius is not finite is hit by no ray in the reference's arithmetic (its discriminant comes out
+    // NaN, or its roots infinite, sphere.cpp:17-50), so it takes no part in the hierarchy at all -- and NaNs must not reach the
+    // comparators below, which would no longer be strict weak orderings.
+    std::vector<char> usable(n, 0);
+    std::vector<float> mags(n, 0.0f), sorted;
+    for (int i = 0; i < n; ++i) {
+        usable[i] = std::isfinite(cx[i]) && std::isfinite(cy[i]) && std::isfinite(cz[i]) && std::isfinite(radius[i]);
+        if (usable[i]) { mags[i] = std::fabs(radius[i]); sorted.push_back(mags[i]); }
+    }
+    float median = 0.0f;
+    if (!sorted.empty()) { std::nth_element(sorted.begin(), sorted.begin() + sorted.size() / 2, sorted.end()); median = sorted[sorted.size() / 2]; }
     bvh_detail::Builder b{ cx, cy, cz, radius, out, {} };
     // "large next to the rest": more than eight median radii; the largest ones first, at most kBvhMaxBig
     std::vector<uint32_t> candidates;
-    for (int i = 0; i < n; ++i) if (mags[i] > 8.0f * median) candidates.push_back((uint32_t)i);
+    for (int i = 0; i < n; ++i) if (usable[i] && mags[i] > 8.0f * median) candidates.push_back((uint32_t)i);
     std::sort(candidates.begin(), candidates.end(), [&](uint32_t p, uint32_t q) { return mags[p] > mags[q] || (mags[p] == mags[q] && p < q); });
     if ((int)candidates.size() > kBvhMaxBig) candidates.resize(kBvhMaxBig);
     std::vector<char> is_big(n, 0);
     for (uint32_t i : candidates) is_big[i] = 1;
-    for (int i = 0; i < n; ++i) (is_big[i] ? out->big : b.order).push_back((uint32_t)i);
+    for (int i = 0; i < n; ++i) if (usable[i]) (is_big[i] ? out->big : b.order).push_back((uint32_t)i);
     out->nodes.resize(2);
     if (b.order.empty()) {
         // nothing left for the tree: an empty leaf that no ray can enter

@@ -240,6 +240,9 @@ int rt_encode_ppm_device(rt_context* ctx, const int32_t* d_irgb, int width, int 
     a.blocks = (a.pixels + kPpmPxPerBlock - 1) / kPpmPxPerBlock;
     a.header_len = snprintf(a.header, sizeof a.header, "P3\n%d %d\n255\n", width, height);
     const size_t off_bytes = ((size_t)a.blocks + 1) * sizeof(unsigned long long), need = off_bytes + (size_t)a.blocks * sizeof(uint32_t);
+    // the write pass of the call before may still be reading the context's block offsets on another stream
+    if (ctx->ppm_pending && st != ctx->ppm_stream) HIP_TRY(ctx, hipStreamSynchronize(ctx->ppm_stream));
+    ctx->ppm_pending = false;
     if (ctx->ppm_scratch_bytes < need) {
         (void)hipFree(ctx->d_ppm_scratch); ctx->d_ppm_scratch = nullptr; ctx->ppm_scratch_bytes = 0;
         HIP_TRY(ctx, hipMalloc(&ctx->d_ppm_scratch, need));
@@ -258,6 +261,7 @@ int rt_encode_ppm_device(rt_context* ctx, const int32_t* d_irgb, int width, int 
     if (!d_text || cap < *bytes) return fail(ctx, RT_ERR_TOO_LARGE, "rt_encode_ppm_device: the text needs %lld bytes, capacity is %lld", (long long)*bytes, (long long)cap);
     hipLaunchKernelGGL(k_ppm_write, dim3(a.blocks), dim3(kPpmBlock), 0, st, a);
     HIP_TRY(ctx, hipGetLastError());
+    ctx->ppm_pending = true; ctx->ppm_stream = st;
     return RT_OK;
 }
 

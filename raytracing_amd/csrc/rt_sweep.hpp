@@ -17,7 +17,7 @@
 
 static constexpr int kBlock = 256;          // 4 waves; each wave owns an 8x8 pixel tile
 static constexpr int kLdsBytesPerSphere = 40;
-static constexpr int kMaxLdsSpheres = 1536; // 60 KB of LDS per block -> at least two blocks per CU
+static constexpr int kMaxLdsSpheres = 1536; // 60 KB of scene records per block; with the 32 KB of mask words of a 512-thread block (92 KB) one block per CU at this size, three at the 487 spheres of the final scene
 
 // Compact owned row r -> image row y (from the top).
 __device__ __forceinline__ int owned_row_to_y2(int band_rows, int band_first, int band_step, int r)

@@ -385,7 +385,8 @@ int trace_prepare(rt_context* ctx, const RenderFrame& f, TracePlan* plan)
     if (bpc == 0) {
         int nb = 0;
         hipError_t e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, trace_kernel(t), kTraceBlock, t.shmem);
-        if (e != hipSuccess || nb <= 0) nb = 1;
+        if (e != hipSuccess) return fail(ctx, RT_ERR_HIP, "occupancy query for the render kernel (%zu bytes of LDS per block) failed: %s", t.shmem, hipGetErrorString(e));
+        if (nb <= 0) return fail(ctx, RT_ERR_TOO_LARGE, "the render kernel does not fit a compute unit with %zu bytes of LDS per block (%d spheres)", t.shmem, ctx->n);
         bpc = nb;
     }
     t.blocks_per_cu = bpc;

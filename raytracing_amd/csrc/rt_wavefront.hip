@@ -193,7 +193,13 @@ int wavefront_batch(rt_context* ctx, const RenderFrame& f, const SampleBatch& b)
     const size_t wshmem = (wl ? ((size_t)ctx->n * 20 + 15) / 16 * 16 : 0) + (size_t)(kTraceBlock / 64) * kSuperChunkWords * 64 * sizeof(uint32_t);
     int& wbpc = ctx->wf_blocks_per_cu[(wl ? 1 : 0) + (wp ? 2 : 0)];
     auto ikern = wl ? (wp ? k_wf_intersect<true, true> : k_wf_intersect<true, false>) : (wp ? k_wf_intersect<false, true> : k_wf_intersect<false, false>);
-    if (wbpc == 0) { int nb = 0; if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, ikern, kTraceBlock, wshmem) != hipSuccess || nb <= 0) nb = 1; wbpc = nb; }
+    if (wbpc == 0) {
+        int nb = 0;
+        const hipError_t e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, ikern, kTraceBlock, wshmem);
+        if (e != hipSuccess) return fail(ctx, RT_ERR_HIP, "occupancy query for the intersect kernel (%zu bytes of LDS per block) failed: %s", wshmem, hipGetErrorString(e));
+        if (nb <= 0) return fail(ctx, RT_ERR_TOO_LARGE, "the intersect kernel does not fit a compute unit with %zu bytes of LDS per block (%d spheres)", wshmem, ctx->n);
+        wbpc = nb;
+    }
     const unsigned igrid_cap = (unsigned)(ctx->num_cu * wbpc);
     // queue 0 is filled by k_wf_init; then intersect/shade alternate between the two queues
     w.q_in = ctx->wf_q[1]; w.q_out = ctx->wf_q[0]; w.n_in = ctx->wf_n + 1; w.n_out = ctx->wf_n + 0;

@@ -144,6 +144,17 @@ def test_sphere_hierarchy_invariants():
     ground = R.final_scene_table()
     _, _, big, _ = build_hierarchy(ground)
     assert 0 in big                      # the r = 1000 ground sphere is tested directly, not boxed
+    # spheres with a non-finite centre or radius (no ray hits them in the reference's arithmetic) stay out of the hierarchy
+    # and leave it well formed
+    odd = R.final_scene_table().copy()
+    bad = [3, 40, 41, 200, 486]
+    odd[3, 0] = np.nan; odd[40, 2] = np.inf; odd[41, 1] = -np.inf; odd[200, 3] = np.nan; odd[486, 3] = np.inf
+    nodes, leaf, big, depth = build_hierarchy(odd)
+    listed = sorted(list(leaf) + list(big))
+    assert listed == [i for i in range(len(odd)) if i not in bad]
+    assert np.isfinite(nodes[:, 0:7]).all() and depth + 2 <= 24
+    nodes, leaf, big, depth = build_hierarchy(np.array([[np.nan, 0, 0, 1.0, 0, 0.5, 0.5, 0.5, 0]]))      # nothing usable at all
+    assert len(big) == 0
 
 
 def test_format_ppm_reproduces_the_file_the_reference_wrote():

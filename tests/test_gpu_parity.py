@@ -467,7 +467,7 @@ def test_random_scenes_match_oracle_in_all_modes(rt):
     bit for bit (image, quantised integers, ray count and the RenderStats counters)."""
     rng = np.random.default_rng(20240607)
     W, H, S = 40, 24, 3
-    for case, n in enumerate([1, 2, 5, 31, 32, 33, 64, 65, 200, 513, 1537, 1600]):
+    for case, n in enumerate([1, 2, 5, 31, 32, 33, 64, 65, 200, 513, 1000, 1536, 1537, 1600, 4000, 4097]):      # 1000 / 1536: more than 64 KB of LDS per block; 4000 / 4097: either side of the wavefront kernel's LDS limit
         table = _random_scene(rng, n)
         look_from = rng.uniform(-4.0, 4.0, size=3)
         look_at = rng.uniform(-1.0, 1.0, size=3)
@@ -756,3 +756,58 @@ def test_device_pointer_form_on_a_side_stream(rt):
     rt.render_device(p, d_rgb.data_ptr(), 0, side.cuda_stream)
     rt.stats()
     assert mismatch(d_rgb.cpu().numpy(), want_rgb) == 0
+
+
+def test_two_streams_on_one_context(rt):
+    """Two renders enqueued back to back on different streams share the context's buffers (counters, samples, staging rows):
+    the second has to wait for the first.  Both images must come out right."""
+    import torch
+    rt.upload_scene(R.final_scene_table())
+    rt.set_camera(R.final_camera(320, 200))
+    pa, pb = rt.params(320, 200, 24, seed=5), rt.params(320, 200, 2, seed=6)
+    want_a, want_b = rt.render(pa), rt.render(pb)
+    a = torch.zeros((200, 320, 3), dtype=torch.float32, device="cuda")
+    b = torch.zeros((200, 320, 3), dtype=torch.float32, device="cuda")
+    sa, sb = torch.cuda.Stream(), torch.cuda.Stream()
+    torch.cuda.synchronize()
+    for _ in range(3):
+        a.zero_(); b.zero_(); torch.cuda.synchronize()
+        rt.render_device(pa, a.data_ptr(), 0, sa.cuda_stream)        # long one first
+        rt.render_device(pb, b.data_ptr(), 0, sb.cuda_stream)        # at once on another stream
+        rays_b, _ = rt.stats()
+        torch.cuda.synchronize()
+        assert rays_b == want_b[2]
+        assert mismatch(a.cpu().numpy(), want_a[0]) == 0 and mismatch(b.cpu().numpy(), want_b[0]) == 0
+    # the PPM encoder's block offsets are context state too
+    ia = torch.from_numpy(want_a[1]).cuda(); ib = torch.from_numpy(want_b[1][:50]).cuda()
+    na, nb = rt.encode_ppm_device(ia.data_ptr(), 320, 200), rt.encode_ppm_device(ib.data_ptr(), 320, 50)
+    ta, tb = torch.zeros(na, dtype=torch.uint8, device="cuda"), torch.zeros(nb, dtype=torch.uint8, device="cuda")
+    rt.encode_ppm_device(ia.data_ptr(), 320, 200, ta.data_ptr(), na, sa.cuda_stream)
+    rt.encode_ppm_device(ib.data_ptr(), 320, 50, tb.data_ptr(), nb, sb.cuda_stream)
+    torch.cuda.synchronize()
+    assert ta.cpu().numpy().tobytes() == R.format_ppm(want_a[1]) and tb.cpu().numpy().tobytes() == R.format_ppm(want_b[1][:50])
+
+
+def test_non_finite_spheres_are_never_hit(rt):
+    """Spheres whose centre or radius is NaN or infinite: no ray hits them in the reference's arithmetic (sphere.cpp:17-50), and
+    they must neither disturb the filters nor the hierarchy.  Every kernel organisation against the CPU oracle."""
+    rng = np.random.default_rng(99)
+    table = _random_scene(rng, 90)
+    table[[3, 17, 40], 0] = [np.nan, np.inf, -np.inf]
+    table[[5, 50], 1] = [np.inf, np.nan]
+    table[[60, 61], 2] = [np.nan, np.inf]
+    table[[70, 71, 72], 3] = [np.nan, np.inf, -np.inf]
+    W, H, S = 40, 24, 3
+    ocam = O.make_camera((3.0, 2.0, 4.0), (0.0, 0.0, 0.0), (0.0, 1.0, 0.0), 50.0, np.float32(W) / np.float32(H), 0.1, 5.0)
+    pod = R.CameraPod()
+    for dst, src in (("origin", "origin"), ("lower_left_corner", "llc"), ("horizontal", "horiz"), ("vertical", "vert"), ("u", "u"), ("v", "v"), ("w", "w")):
+        vec = getattr(ocam, src)
+        getattr(pod, dst)[:] = [vec.x, vec.y, vec.z]
+    pod.lens_radius = ocam.lens_radius
+    rt.upload_scene(table)
+    rt.set_camera(pod)
+    want, wq, wrays, wcount = O.render_counted(O.SceneArrays.from_table(table), ocam, W, H, S, O.usrc_philox(31))
+    for mode in (R.MODE_MEGAKERNEL, R.MODE_WAVEFRONT, R.MODE_PIXEL, R.MODE_BVH):
+        rgb, irgb, rays, _ = rt.render(rt.params(W, H, S, seed=31, mode=mode))
+        assert rays == wrays and rt.counters() == wcount, mode
+        assert mismatch(rgb, want) == 0 and np.array_equal(irgb, wq), mode
