@@ -129,6 +129,18 @@ int rt_render_counters(rt_context *ctx, rt_counters *out);
 int rt_render(rt_context *ctx, const rt_params *p, float *h_rgb_mean, int32_t *h_irgb,
               uint64_t *rays, float *kernel_ms);
 
+/* One image over several GPUs of the node: the band decomposition of performance.h:133-155 / main_modern.cpp:197-219 with
+ * GPUs in place of pool threads.  ctx[0..n) are contexts (normally one per GPU; several on one GPU also work) that all hold
+ * the same scene and camera.  p describes the whole image; its band_first / band_step are ignored: context k renders bands
+ * k, k + n, k + 2n, ... of p->band_rows rows each (1-row bands spread cheap sky rows and expensive sphere rows evenly).  One
+ * host thread per context runs the render and copies that context's rows straight into their places in the caller's
+ * images (a strided device-to-host copy per context -- the image is wanted on the host for output.ppm, so a hop through
+ * GPU 0 would only add a copy).  h_irgb / h_rgb_mean: whole image, height x width x 3, either may be NULL.  rays: sum over
+ * the contexts; kernel_ms: n values, one per context (may be NULL).  The assembled image is the one a single context
+ * renders, bit for bit, because every uniform is keyed on the pixel. */
+int rt_render_multi(rt_context **ctx, int n, const rt_params *p, float *h_rgb_mean, int32_t *h_irgb, uint64_t *rays,
+                    float *kernel_ms);
+
 /* ---- scene setup helpers (host side, untimed) --------------------------------------------- */
 /* RandomScene() (main.cpp:41-83) generalised to a (2*half_extent)^2 grid of candidate cells with an
  * explicit, compiler-independent draw order: candidate t = (a + half_extent) * 2*half_extent +

@@ -5,10 +5,10 @@ gfx950).  The library is the product; this package only loads it, marshals plain
 splits the image into bands across ranks.  There is no CPU fallback: if the HIP library is
 missing or no GPU is visible, calls raise.
 """
-from ._lib import (scene_grid, RtError, Camera, CameraPod, Params, Renderer, device_count, format_ppm, load_library,
+from ._lib import (scene_grid, render_multi, RtError, Camera, CameraPod, Params, Renderer, device_count, format_ppm, load_library,
                    write_ppm, write_ppm_binary, MODE_MEGAKERNEL, MODE_WAVEFRONT, MODE_PIXEL, MODE_BVH, LAMBERTIAN, METAL, DIELECTRIC)
 from .scenes import final_scene_table, three_sphere_table, final_camera, three_camera, make_camera
 
-__all__ = ["scene_grid", "RtError", "Camera", "CameraPod", "Params", "Renderer", "device_count", "format_ppm", "load_library",
+__all__ = ["scene_grid", "render_multi", "RtError", "Camera", "CameraPod", "Params", "Renderer", "device_count", "format_ppm", "load_library",
            "write_ppm", "write_ppm_binary", "MODE_MEGAKERNEL", "MODE_WAVEFRONT", "MODE_PIXEL", "MODE_BVH", "LAMBERTIAN", "METAL", "DIELECTRIC",
            "final_scene_table", "three_sphere_table", "final_camera", "three_camera", "make_camera"]

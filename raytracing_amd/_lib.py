@@ -13,7 +13,7 @@ LAMBERTIAN, METAL, DIELECTRIC = 0, 1, 2
 
 # every symbol include/rt_amd.h declares
 EXPORTS = ["rt_device_count", "rt_create", "rt_destroy", "rt_last_error", "rt_upload_scene", "rt_set_camera",
-           "rt_owned_rows", "rt_owned_pixels", "rt_render_device", "rt_render_stats", "rt_render_counters", "rt_render",
+           "rt_owned_rows", "rt_owned_pixels", "rt_render_device", "rt_render_stats", "rt_render_counters", "rt_render", "rt_render_multi",
            "rt_scene_grid", "rt_build_hierarchy", "rt_format_ppm", "rt_write_ppm", "rt_write_ppm_binary", "rt_encode_ppm_device", "rt_encode_ppm_device_noalloc", "rt_write_ppm_device", "rt_test_sphere_hit", "rt_test_scatter", "rt_test_get_ray",
            "rt_test_helpers", "rt_test_philox"]
 
@@ -94,6 +94,7 @@ def load_library():
     L.rt_render_stats.argtypes = [vp, C.POINTER(C.c_uint64), C.POINTER(C.c_float)]
     L.rt_render_counters.argtypes = [vp, C.POINTER(Counters)]
     L.rt_render.argtypes = [vp, C.POINTER(Params), fp, ip, C.POINTER(C.c_uint64), C.POINTER(C.c_float)]
+    L.rt_render_multi.argtypes = [C.POINTER(vp), C.c_int, C.POINTER(Params), fp, ip, C.POINTER(C.c_uint64), fp]
     L.rt_scene_grid.argtypes = [C.c_uint64, C.c_int, C.c_int, fp, C.c_int, C.POINTER(C.c_int)]
     L.rt_build_hierarchy.argtypes = [C.c_int, fp, fp, fp, fp, fp, C.c_int, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32), C.POINTER(C.c_int32)]
     L.rt_format_ppm.argtypes = [ip, C.c_int, C.c_int, C.c_char_p, C.c_int64]
@@ -314,6 +315,22 @@ class Renderer:
         u32 = C.POINTER(C.c_uint32)
         self._check(self._L.rt_test_philox(self._ctx, n, c.ctypes.data_as(u32), k.ctypes.data_as(u32), out.ctypes.data_as(u32)))
         return out.reshape(n, 4)
+
+
+def render_multi(renderers, p):
+    """rt_render_multi: one image over the contexts of `renderers` (each holding the same scene and camera).
+    Returns (rgb_mean[h,w,3] f32, irgb[h,w,3] i32, rays, [kernel_ms per context])."""
+    L = load_library()
+    n = len(renderers)
+    ctxs = (C.c_void_p * n)(*[r._ctx for r in renderers])
+    rgb = np.zeros((p.height, p.width, 3), dtype=np.float32)
+    irgb = np.zeros((p.height, p.width, 3), dtype=np.int32)
+    rays = C.c_uint64(0)
+    ms = np.zeros(n, dtype=np.float32)
+    rc = L.rt_render_multi(ctxs, n, C.byref(p), _fp(rgb), _ip(irgb), C.byref(rays), _fp(ms))
+    if rc != 0:
+        raise RtError(rc, L.rt_last_error(renderers[0]._ctx).decode() if n else L.rt_last_error(None).decode())
+    return rgb, irgb, rays.value, [float(x) for x in ms]
 
 
 def scene_grid(seed=42, half_extent=75, max_small=19996):

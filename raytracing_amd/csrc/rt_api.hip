@@ -7,6 +7,7 @@
 #include <cstring>
 #include <new>
 #include <string>
+#include <thread>
 #include <type_traits>
 #include <vector>
 #include "rt_internal.hpp"
@@ -329,3 +330,67 @@ int rt_render(rt_context* ctx, const rt_params* p, float* h_rgb_mean, int32_t* h
 }
 
 }  // extern "C"
+namespace {
+// Renders context k's share of the image and copies its rows into the caller's whole-image arrays.
+int render_share(rt_context* ctx, int k, int n, const rt_params& whole, float* h_rgb_mean, int32_t* h_irgb, uint64_t* rays, float* ms)
+{
+    rt_params p = whole;
+    p.band_first = k; p.band_step = n;
+    const int64_t rows = rt_owned_rows(&p);
+    *rays = 0; *ms = 0.0f;
+    if (rows == 0) return RT_OK;
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    const size_t npx = (size_t)rows * p.width;
+    if (h_rgb_mean && ctx->out_rgb_bytes < npx * 12) {
+        (void)hipFree(ctx->d_out_rgb); ctx->d_out_rgb = nullptr; ctx->out_rgb_bytes = 0;
+        HIP_TRY(ctx, hipMalloc(&ctx->d_out_rgb, npx * 12)); ctx->out_rgb_bytes = npx * 12;
+    }
+    if (h_irgb && ctx->out_irgb_bytes < npx * 12) {
+        (void)hipFree(ctx->d_out_irgb); ctx->d_out_irgb = nullptr; ctx->out_irgb_bytes = 0;
+        HIP_TRY(ctx, hipMalloc(&ctx->d_out_irgb, npx * 12)); ctx->out_irgb_bytes = npx * 12;
+    }
+    int rc = rt_render_device(ctx, &p, h_rgb_mean ? ctx->d_out_rgb : nullptr, h_irgb ? ctx->d_out_irgb : nullptr, nullptr);
+    if (rc == RT_OK) rc = rt_render_stats(ctx, rays, ms);
+    if (rc != RT_OK) return rc;
+    // Packed rows of this context -> their places in the image.  Its full bands are band_rows * width * 12 bytes each, one
+    // every n bands of the image: one strided copy; a shorter last band (height not a multiple of band_rows) goes separately.
+    const size_t band_bytes = (size_t)p.band_rows * p.width * 12;
+    const int64_t nbands = ((int64_t)p.height + p.band_rows - 1) / p.band_rows;
+    int64_t full = 0; int64_t tail_rows = 0, tail_band = -1;
+    for (int64_t b = k; b < nbands; b += n) {
+        if ((b + 1) * p.band_rows <= p.height) ++full; else { tail_rows = p.height - b * p.band_rows; tail_band = b; }
+    }
+    auto scatter = [&](void* host, const void* dev) -> int {
+        char* h = static_cast<char*>(host) + (size_t)k * band_bytes;
+        if (full > 0) HIP_TRY(ctx, hipMemcpy2D(h, (size_t)n * band_bytes, dev, band_bytes, band_bytes, (size_t)full, hipMemcpyDeviceToHost));
+        if (tail_band >= 0) HIP_TRY(ctx, hipMemcpy(static_cast<char*>(host) + (size_t)tail_band * band_bytes, static_cast<const char*>(dev) + (size_t)full * band_bytes, (size_t)tail_rows * p.width * 12, hipMemcpyDeviceToHost));
+        return RT_OK;
+    };
+    if (h_rgb_mean) { rc = scatter(h_rgb_mean, ctx->d_out_rgb); if (rc != RT_OK) return rc; }
+    if (h_irgb) { rc = scatter(h_irgb, ctx->d_out_irgb); if (rc != RT_OK) return rc; }
+    return RT_OK;
+}
+}  // namespace
+
+extern "C" int rt_render_multi(rt_context** ctx, int n, const rt_params* p, float* h_rgb_mean, int32_t* h_irgb, uint64_t* rays, float* kernel_ms)
+{
+    if (!ctx || n <= 0) return fail(nullptr, RT_ERR_INVALID, "rt_render_multi: no contexts");
+    for (int k = 0; k < n; ++k) if (!ctx[k]) return fail(nullptr, RT_ERR_INVALID, "rt_render_multi: context %d is null", k);
+    for (int k = 0; k < n; ++k) for (int j = 0; j < k; ++j) if (ctx[j] == ctx[k]) return fail(ctx[0], RT_ERR_INVALID, "rt_render_multi: context %d is listed twice", k);
+    if (!params_ok(p)) return fail(ctx[0], RT_ERR_INVALID, "rt_render_multi: invalid parameters");
+    for (int k = 0; k < n; ++k) if (!ctx[k]->n || !ctx[k]->have_camera) return fail(ctx[0], RT_ERR_STATE, "rt_render_multi: context %d has no scene or camera", k);
+    std::vector<int> rc(n, RT_OK); std::vector<uint64_t> r(n, 0); std::vector<float> ms(n, 0.0f);
+    std::vector<std::thread> workers;
+    // one host thread per context; HIP's current device is per thread
+    for (int k = 1; k < n; ++k) workers.emplace_back([&, k] { rc[k] = render_share(ctx[k], k, n, *p, h_rgb_mean, h_irgb, &r[k], &ms[k]); });
+    rc[0] = render_share(ctx[0], 0, n, *p, h_rgb_mean, h_irgb, &r[0], &ms[0]);
+    for (std::thread& t : workers) t.join();
+    uint64_t total = 0;
+    for (int k = 0; k < n; ++k) {
+        if (rc[k] != RT_OK) { if (k != 0) ctx[0]->error = "context " + std::to_string(k) + ": " + ctx[k]->error; return rc[k]; }
+        total += r[k];
+        if (kernel_ms) kernel_ms[k] = ms[k];
+    }
+    if (rays) *rays = total;
+    return RT_OK;
+}

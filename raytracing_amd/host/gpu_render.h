@@ -4,6 +4,7 @@
 // the C ABI underneath reports them by status code.
 #pragma once
 #include <cstdint>
+#include <memory>
 #include <stdexcept>
 #include <string>
 #include <vector>
@@ -118,6 +119,8 @@ public:
         return total_ms;
     }
 
+    rt_context* Context() const { return m_ctx; }
+
 private:
     void Check(int rc, const char* what) const
     {
@@ -135,6 +138,30 @@ inline RenderResult RenderOnGpu(const Hittable* world, const Camera& cam, int nx
     rt_counters c{};
     out.kernel_ms = gpu.Render(GpuRenderer::Params(nx, ny, ns, seed), out.irgb.data(), &c);
     out.rays = c.rays_traced;
+    return out;
+}
+
+// The same image over `devices` GPUs of the node (0 = all that are visible): one context per GPU, every one holding the
+// scene and the camera, single rows dealt round-robin (rt_render_multi).  The thread pool over tiles of
+// main_modern.cpp:197-219 with GPUs as the workers.
+inline RenderResult RenderOnGpus(const Hittable* world, const Camera& cam, int nx, int ny, int ns, uint64_t seed, int devices)
+{
+    int visible = 0;
+    if (rt_device_count(&visible) != RT_OK || visible <= 0) throw std::runtime_error(std::string("rt_device_count: ") + rt_last_error(nullptr));
+    if (devices <= 0) devices = visible;
+    if (devices > visible) throw std::invalid_argument("RenderOnGpus: " + std::to_string(devices) + " GPUs asked for, " + std::to_string(visible) + " visible");
+    std::vector<std::unique_ptr<GpuRenderer>> gpus;
+    for (int d = 0; d < devices; ++d) gpus.emplace_back(new GpuRenderer(world, cam, d));
+    std::vector<rt_context*> ctx;
+    for (auto& g : gpus) ctx.push_back(g->Context());
+    RenderResult out;
+    out.irgb.resize((size_t)nx * ny * 3);
+    rt_params p = GpuRenderer::Params(nx, ny, ns, seed);
+    p.band_rows = 1;
+    std::vector<float> ms(devices, 0.0f);
+    if (rt_render_multi(ctx.data(), devices, &p, nullptr, out.irgb.data(), &out.rays, ms.data()) != RT_OK)
+        throw std::runtime_error(std::string("rt_render_multi: ") + rt_last_error(ctx[0]));
+    for (float m : ms) out.kernel_ms = m > out.kernel_ms ? m : out.kernel_ms;       // the slowest GPU
     return out;
 }
 

@@ -2,7 +2,9 @@
 // class surface (main.cpp:109-116), the pixel loop (main.cpp:118-146) replaced by one GPU render
 // call, and output.ppm written in the same ASCII P3 format.
 //
-//   raytracing_amd [nx ny ns [output.ppm [seed]]]      defaults: 400 300 5 output.ppm 0  (main.cpp:87-89)
+//   raytracing_amd [nx ny ns [output.ppm [seed [gpus]]]]      defaults: 400 300 5 output.ppm 0 1  (main.cpp:87-89)
+//
+// gpus > 1 (or 0 = every visible GPU) splits the rows over that many GPUs of the node; the image does not depend on it.
 //
 // Differences from the reference, on purpose: the output file is created/truncated (the reference
 // opens it with std::fstream's default mode and silently writes nothing when it does not exist);
@@ -24,6 +26,8 @@ int main(int argc, char const* argv[])
     if (argc >= 4) { nx = std::atoi(argv[1]); ny = std::atoi(argv[2]); ns = std::atoi(argv[3]); }
     if (argc >= 5) path = argv[4];
     if (argc >= 6) seed = std::strtoull(argv[5], nullptr, 10);
+    int gpus = 1;
+    if (argc >= 7) gpus = std::atoi(argv[6]);
 
     Hittable* world = RandomScene();
     const Vec3 lookFrom(13.0f, 2.0f, 3.0f), lookAt(0.0f, 0.0f, 0.0f);
@@ -32,7 +36,7 @@ int main(int argc, char const* argv[])
 
     try {
         const auto t0 = std::chrono::steady_clock::now();
-        const rtamd::RenderResult img = rtamd::RenderOnGpu(world, camera, nx, ny, ns, seed);
+        const rtamd::RenderResult img = gpus == 1 ? rtamd::RenderOnGpu(world, camera, nx, ny, ns, seed) : rtamd::RenderOnGpus(world, camera, nx, ny, ns, seed, gpus);
         const double wall = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
         if (rt_write_ppm(path.c_str(), img.irgb.data(), nx, ny) != RT_OK) { std::fprintf(stderr, "%s\n", rt_last_error(nullptr)); return 1; }
         std::printf("Rays traced: %llu\nKernel time: %.3f ms\nRays per second: %.0f\nWall (setup + render + copy): %.3f s\n",

@@ -811,3 +811,34 @@ def test_non_finite_spheres_are_never_hit(rt):
         rgb, irgb, rays, _ = rt.render(rt.params(W, H, S, seed=31, mode=mode))
         assert rays == wrays and rt.counters() == wcount, mode
         assert mismatch(rgb, want) == 0 and np.array_equal(irgb, wq), mode
+
+
+def test_render_multi_assembles_the_single_context_image(rt):
+    """rt_render_multi: several contexts (here on whatever GPUs are visible, and several on GPU 0) render interleaved bands on
+    one host thread each and copy their rows into the caller's image; the result is the single-context image bit for bit."""
+    table = R.final_scene_table()
+    W, H, S = 200, 131, 3                       # 131 rows: a short last band for every band height used below
+    rt.upload_scene(table)
+    rt.set_camera(R.final_camera(W, H))
+    want = rt.render(rt.params(W, H, S, seed=8))
+    devices = R.device_count()
+    for n, band in ((1, 8), (devices, 1), (3, 1), (4, 7), (5, 40)):
+        rs = []
+        for k in range(n):
+            r = R.Renderer(k % devices)
+            r.upload_scene(table)
+            r.set_camera(R.final_camera(W, H))
+            rs.append(r)
+        rgb, irgb, rays, ms = R.render_multi(rs, rt.params(W, H, S, seed=8, band_rows=band))
+        assert rays == want[2] and len(ms) == n and all(m > 0 for m in ms[:min(n, (H + band - 1) // band)])
+        assert mismatch(rgb, want[0]) == 0 and np.array_equal(irgb, want[1]), (n, band)
+        for r in rs:
+            r.close()
+    # misuse is reported, not crashed on
+    fresh = R.Renderer(0)
+    with pytest.raises(R.RtError) as e:
+        R.render_multi([rt, fresh], rt.params(W, H, S))
+    assert e.value.code == -4
+    with pytest.raises(R.RtError):
+        R.render_multi([rt, rt], rt.params(W, H, S))
+    fresh.close()

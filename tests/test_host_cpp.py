@@ -43,6 +43,13 @@ def test_drop_in_main_writes_the_same_ppm_as_the_python_path(tmp_path):
     rt.close()
     assert open(path, "rb").read() == R.format_ppm(irgb)
     assert f"Rays traced: {rays}" in out.stdout
+    # the same image over every visible GPU of the node (rt_render_multi): the file does not change
+    path_all = str(tmp_path / "output_all_gpus.ppm")
+    multi = subprocess.run([_built("raytracing_amd"), "96", "64", "3", path_all, "5", "0"], capture_output=True, text=True, timeout=120)
+    assert multi.returncode == 0, multi.stderr
+    assert open(path_all, "rb").read() == open(path, "rb").read() and f"Rays traced: {rays}" in multi.stdout
+    too_many = subprocess.run([_built("raytracing_amd"), "96", "64", "3", path_all, "5", "99"], capture_output=True, text=True, timeout=120)
+    assert too_many.returncode != 0 and "visible" in too_many.stderr
     # error path: unwritable output
     bad = subprocess.run([_built("raytracing_amd"), "8", "8", "1", "/nonexistent_dir/x.ppm"], capture_output=True, text=True, timeout=120)
     assert bad.returncode != 0
