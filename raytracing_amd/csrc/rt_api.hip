@@ -129,13 +129,18 @@ int rt_upload_scene(rt_context* ctx, int n, const float* cx, const float* cy, co
         }
     }
     // Full chunks of 32 judged spheres whose R lie within 20 % of each other are stored normalised by rho = sqrt(max R)
-    // (rounded up): (cx / rho, cz / rho, 1 / rho, 0); see filter_norm in rt_sweep.hpp.
+    // (rounded up), see filter_norm in rt_sweep.hpp.
     for (int base = 0; base + 32 <= n_pad && base + 32 <= n; base += 32) {
         float rmax = 0.0f, rmin = FLT_MAX; bool all = true;
         for (int i = base; i < base + 32; ++i) { all = all && judged_flag[i]; rmax = std::max(rmax, Rof[i]); rmin = std::min(rmin, Rof[i]); }
         if (!all || rmin < 0.8f * rmax) continue;
         const double rho = std::sqrt((double)rmax) * (1.0 + 1e-7);
-        for (int i = base; i < base + 32; ++i) prec[i] = make_float4((float)(cx[i] / rho), (float)(cz[i] / rho), (float)(1.0 / rho), 0.0f);
+        // compact layout inside the chunk's 32 float4 slots: 32 pairs (cx / rho, cz / rho) in the first 64 floats, 1 / rho in float 64,
+        // so that one 16-dword scalar load brings eight spheres and half as many bytes stream through the scalar cache
+        float* slot = reinterpret_cast<float*>(&prec[base]);
+        for (int k = 0; k < 128; ++k) slot[k] = 0.0f;
+        for (int i = 0; i < 32; ++i) { slot[2 * i] = (float)(cx[base + i] / rho); slot[2 * i + 1] = (float)(cz[base + i] / rho); }
+        slot[64] = (float)(1.0 / rho);
         force[n_words + (base >> 9)] |= 0x8000u >> ((base >> 5) & 15);
     }
     const float plane_s0 = 1e-30f;

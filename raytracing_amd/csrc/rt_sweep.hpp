@@ -80,7 +80,10 @@ static constexpr int kChunkItems = 512;
 static constexpr int kStagingRows = 9;
 static constexpr int kTraceBlock = 512;         // 8 waves share one LDS copy of the scene records
 __device__ __forceinline__ float staged_load(const float* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
-static constexpr int kSuperChunkWords = 16;                     // 32-sphere mask words kept per lane between exact passes (512 spheres)
+#ifndef RT_SUPER_WORDS
+#define RT_SUPER_WORDS 16
+#endif
+static constexpr int kSuperChunkWords = RT_SUPER_WORDS;         // 32-sphere mask words kept per lane between exact passes (16 words = 512 spheres); 16, 8 or 4
 static constexpr float kRaySlack = 160.0f * 5.9604645e-08f;   // per-ray slack, relative to |o|^2
 static constexpr float kPlaneRaySlack = 144.0f * 5.9604645e-08f;
 static constexpr float kPlaneScale = 0x1p44f;                   // scaling of the plane filter's per-ray constants; its records carry 2^88 R
@@ -198,21 +201,28 @@ __device__ __forceinline__ void closest_hit(const RayD& ray, float tmin, const S
     };
     typedef const __attribute__((address_space(4))) uint32_t* ConstWord;
     const ConstWord force_k = (ConstWord)(sw.force);
-    // Chunks whose spheres all have (nearly) the same R are stored normalised: record (cx / rho, cz / rho, 1 / rho, 0) with
+    // Chunks whose spheres all have (nearly) the same R are stored normalised: pairs (cx / rho, cz / rho) and one 1 / rho with
     // rho^2 = the largest R of the chunk, and the test becomes q^2 <= 1, q = (cx/rho) ux + (cz/rho) uz - (o.u)/rho.  The
     // threshold is then the same number for every sphere and can sit in a vector register, so a pair costs two FMAs with a
     // scalar operand instead of three (3.7 cycles each here, against 1.65 for an all-VGPR FMA).  Which chunks are stored
     // this way is a bit per chunk, sixteen chunks per word, behind the forced-sphere words.
+    typedef float f16v __attribute__((ext_vector_type(16)));
+    typedef const __attribute__((address_space(4))) f16v* ConstRec16;
     auto filter_norm = [&](int base, float threshold) -> uint32_t {
-        const float nc = nou * prec_k[base].z;
+        // the chunk's slot holds 32 pairs (cx / rho, cz / rho) in its first 64 floats and 1 / rho in float 64
+        const ConstRec16 pairs = (ConstRec16)(prec_k + base);
+        const float nc = nou * prec_k[base + 16].x;
         float acc0 = 0.0f, acc1 = 0.0f;
 #pragma unroll
-        for (int jj = 0; jj < 32; ++jj) {
-            const f4v f = prec_k[base + jj];
-            const float q = fmaf(f.x, ux, fmaf(f.y, uz, nc));
-            float verdict;
-            asm("v_fma_f32 %0, -%1, %1, %2 clamp" : "=v"(verdict) : "v"(q), "v"(threshold));
-            if (jj < 16) acc0 = fmaf(acc0, 2.0f, verdict); else acc1 = fmaf(acc1, 2.0f, verdict);
+        for (int g = 0; g < 4; ++g) {
+            const f16v f = pairs[g];
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                const float q = fmaf(f[2 * i], ux, fmaf(f[2 * i + 1], uz, nc));
+                float verdict;
+                asm("v_fma_f32 %0, -%1, %1, %2 clamp" : "=v"(verdict) : "v"(q), "v"(threshold));
+                if (g < 2) acc0 = fmaf(acc0, 2.0f, verdict); else acc1 = fmaf(acc1, 2.0f, verdict);
+            }
         }
         return ((uint32_t)acc0 << 16) | (uint32_t)acc1;
     };
@@ -228,21 +238,24 @@ __device__ __forceinline__ void closest_hit(const RayD& ray, float tmin, const S
         int words = 0;
         int base = sbase;
         const int send = (sw.n_pad - sbase < 32 * kSuperChunkWords) ? sw.n_pad : sbase + 32 * kSuperChunkWords;
-        const uint32_t normalised = kPlane ? force_k[((sw.n_pad + 31) >> 5) + (sbase >> 9)] : 0u;     // bit (15 - w): word w is stored normalised
+        // one flag word covers 16 chunks (512 spheres); this super-chunk's share of it, bit (kSuperChunkWords - 1 - w): word w is stored normalised
+        constexpr uint32_t kAllWords = (1u << kSuperChunkWords) - 1u;
+        const int flag_shift = kSuperChunkWords * (16 / kSuperChunkWords - 1 - ((sbase / (32 * kSuperChunkWords)) % (16 / kSuperChunkWords)));
+        const uint32_t normalised = kPlane ? (force_k[((sw.n_pad + 31) >> 5) + (sbase >> 9)] >> flag_shift) & kAllWords : 0u;
         const int full_words = (send - sbase) >> 5;
         // two loops with one body each (a single loop choosing between the two unrolled bodies per word makes the
         // register allocator spill twenty registers)
         if (normalised != 0u) {
             for (int w = 0; w < full_words; ++w) {
-                if (((normalised >> (15 - w)) & 1u) == 0u) continue;
+                if (((normalised >> (kSuperChunkWords - 1 - w)) & 1u) == 0u) continue;
                 const uint32_t cand = filter_norm(sbase + 32 * w, threshold88);
                 mask_words[w * 64] = cand;
                 nz |= cand != 0u ? 0x80000000u >> w : 0u;
             }
         }
-        if (normalised != (0xffffu & ~(0xffffu >> full_words))) {
+        if (normalised != (kAllWords & ~(kAllWords >> full_words))) {
             for (int w = 0; w < full_words; ++w) {
-                if (((normalised >> (15 - w)) & 1u) != 0u) continue;
+                if (((normalised >> (kSuperChunkWords - 1 - w)) & 1u) != 0u) continue;
                 const uint32_t cand = filter_bits(sbase + 32 * w, std::integral_constant<int, 32>());
                 mask_words[w * 64] = cand;
                 nz |= cand != 0u ? 0x80000000u >> w : 0u;
@@ -360,6 +373,12 @@ template <bool kLds>
 __device__ __forceinline__ void closest_hit_few(const RayD& ray, float tmin, const SweepScene& sw, const ExactLds& lds,
                                                 unsigned long long live, int lane, float& closest, int& hit)
 {
+    // A lone wave issues one dependent instruction every few cycles, so what a bounce costs here is the LENGTH of its dependency
+    // chains, not the number of instructions: the discriminants of four spheres per lane are formed side by side (four independent
+    // chains, 256 spheres per batch), the square root and the two divisions are paid only for lanes whose line meets a sphere, and
+    // the wave minimum is taken over the few lanes that found a root by reading them out one by one (scalar), not by a
+    // six-step butterfly of cross-lane moves.
+    constexpr int kPerLane = 4;
     while (live != 0ull) {
         const int src = __builtin_ctzll(live);
         live &= live - 1ull;
@@ -372,31 +391,47 @@ __device__ __forceinline__ void closest_hit_few(const RayD& ray, float tmin, con
                  __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, ray.d.z), src)));
         const float qa = dot(r.d, r.d);
         float best = FLT_MAX; int best_k = -1;
-        for (int base = 0; base < sw.n; base += 64) {
-            const int k = base + lane;
-            float b = 0.0f, desc = -1.0f;
-            if (k < sw.n) {
-                const float4 g = kLds ? lds.geom[k] : sw.geom[k];
-                const V3 oc = r.o - mk(g.x, g.y, g.z);
-                b = dot(oc, r.d);
-                const float cc = dot(oc, oc) - exact_r2<kLds>(g, lds, k);
-                desc = b * b - qa * cc;
+        for (int base = 0; base < sw.n; base += 64 * kPerLane) {
+            float b[kPerLane], desc[kPerLane];
+#pragma unroll
+            for (int j = 0; j < kPerLane; ++j) {
+                const int k = base + 64 * j + lane;
+                b[j] = 0.0f; desc[j] = -1.0f;
+                if (k < sw.n) {
+                    const float4 g = kLds ? lds.geom[k] : sw.geom[k];
+                    const V3 oc = r.o - mk(g.x, g.y, g.z);
+                    b[j] = dot(oc, r.d);
+                    const float cc = dot(oc, oc) - exact_r2<kLds>(g, lds, k);
+                    desc[j] = b[j] * b[j] - qa * cc;
+                }
             }
-            if (__any(desc > 0.0f)) {
-                if (desc > 0.0f) {
-                    const float sq = sqrtf(desc);
-                    float temp = (-b - sq) / qa;
-                    if (!(temp < best && temp > tmin)) temp = (-b + sq) / qa;
-                    if (temp < best && temp > tmin) { best = temp; best_k = k; }
+            bool any_positive = false;
+#pragma unroll
+            for (int j = 0; j < kPerLane; ++j) any_positive = any_positive || desc[j] > 0.0f;
+            if (__any(any_positive)) {
+                // ascending sphere index inside the lane, strict comparisons: equal roots stay with the lower index
+#pragma unroll
+                for (int j = 0; j < kPerLane; ++j) {
+                    if (desc[j] > 0.0f) {
+                        const float sq = sqrtf(desc[j]);
+                        float temp = (-b[j] - sq) / qa;
+                        if (!(temp < best && temp > tmin)) temp = (-b[j] + sq) / qa;
+                        if (temp < best && temp > tmin) { best = temp; best_k = base + 64 * j + lane; }
+                    }
                 }
             }
         }
-        // wave minimum of (t, index): smaller t wins, equal t goes to the lower index
-        for (int off = 1; off < 64; off <<= 1) {
-            const float ot = __shfl_xor(best, off); const int ok = __shfl_xor(best_k, off);
-            if (ot < best || (ot == best && (unsigned)ok < (unsigned)best_k)) { best = ot; best_k = ok; }
+        // wave minimum of (t, index) over the lanes that hold a root: smaller t wins, equal t goes to the lower index
+        unsigned long long cand = __ballot(best_k >= 0);
+        float wt = FLT_MAX; int wk = -1;
+        while (cand != 0ull) {
+            const int l = __builtin_ctzll(cand);
+            cand &= cand - 1ull;
+            const float t = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, best), l));
+            const int k = __builtin_amdgcn_readlane(best_k, l);
+            if (t < wt || (t == wt && (unsigned)k < (unsigned)wk)) { wt = t; wk = k; }
         }
-        if (lane == src) { closest = best; hit = best_k; }
+        if (lane == src) { closest = wt; hit = wk; }
     }
 }
 

@@ -143,7 +143,10 @@ __global__ void __launch_bounds__(1024) k_tile_order(const TileArgs a)
 #ifdef RT_SECTION_TIMERS
 #define RT_TRACE_WAVES(kBvh, kLds)      /* the timers' accumulators need the registers */
 #else
-#define RT_TRACE_WAVES(kBvh, kLds) __attribute__((amdgpu_waves_per_eu((kBvh) && (kLds) ? 4 : 6, (kBvh) && (kLds) ? 4 : 6)))
+#ifndef RT_WAVES
+#define RT_WAVES 6
+#endif
+#define RT_TRACE_WAVES(kBvh, kLds) __attribute__((amdgpu_waves_per_eu((kBvh) && (kLds) ? 4 : RT_WAVES, (kBvh) && (kLds) ? 4 : RT_WAVES)))
 #endif
 template <bool kLds, bool kPlane, bool kBvh = false>
 __global__ void __launch_bounds__(kTraceBlock) RT_TRACE_WAVES(kBvh, kLds) k_trace(const TraceArgs a)
