@@ -43,3 +43,13 @@ print("sparse trips: total %d, mean %.2f us per trip; waves with > 20 sparse tri
 fs = (buf[6][live].astype(np.int64) - int(t0)) / 100.0
 fd = (buf[7][live].astype(np.int64) - int(t0)) / 100.0
 print("first sweep starts us: min %.0f median %.0f max %.0f;  second trip's sweep starts us: median %.0f max %.0f" % (fs.min(), np.median(fs), fs.max(), np.median(fd), fd.max()))
+# the stragglers: for the waves that exit last, how the time after the counter ran dry splits into trips with the ordinary sweep and trips with the sparse one
+order = np.argsort(-exit_)[:12]
+print("last waves: exit us | dry us | trips after dry | of them sparse | us in sparse trips | us in ordinary trips | us per ordinary trip")
+for w in order:
+    full = trips[w] - st[w]
+    t_full = (exit_[w] - dry[w]) - sk[w]
+    print("   %7.0f | %6.0f | %3d | %3d | %6.0f | %6.0f | %5.1f" % (exit_[w], dry[w], trips[w], st[w], sk[w], t_full, t_full / max(full, 1)))
+late = exit_ > np.percentile(exit_, 99)
+print("slowest 1 %% of waves: mean trips after dry %.1f, of them sparse %.1f; mean us in sparse %.0f, in ordinary %.0f" %
+      (trips[late].mean(), st[late].mean(), sk[late].mean(), ((exit_ - dry)[late] - sk[late]).mean()))
