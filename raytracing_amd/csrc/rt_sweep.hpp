@@ -213,15 +213,40 @@ __device__ __forceinline__ void closest_hit(const RayD& ray, float tmin, const S
         const ConstRec16 pairs = (ConstRec16)(prec_k + base);
         const float nc = nou * prec_k[base + 16].x;
         float acc0 = 0.0f, acc1 = 0.0f;
-#pragma unroll
-        for (int g = 0; g < 4; ++g) {
-            const f16v f = pairs[g];
+        // Scenes too large for the LDS mirror are also too large for the scalar cache (20 000 spheres: 160 KB of pairs through
+        // 16 KB), and there a scalar load is a trip to L2.  Scalar loads come back out of order, so a wave can only wait for all
+        // that are outstanding: the next eight spheres are requested right AFTER the wait for the current eight (after their
+        // first use) and have the other 31 instructions of the group to arrive; two sets of sixteen scalar registers alternate
+        // (20 000-sphere scene 378 -> 357 ms at 32 spp).  Where the records stay in the scalar cache the sixteen extra registers
+        // cost more than the overlap gains (487 spheres: 89 -> 95 ms, ten more spilled registers), so that form loads and waits.
+        constexpr bool kPipelinedRecords = !kLds;
+        auto eight = [&](const f16v& f, int g, auto&& after_first) {
 #pragma unroll
             for (int i = 0; i < 8; ++i) {
                 const float q = fmaf(f[2 * i], ux, fmaf(f[2 * i + 1], uz, nc));
                 float verdict;
                 asm("v_fma_f32 %0, -%1, %1, %2 clamp" : "=v"(verdict) : "v"(q), "v"(threshold));
                 if (g < 2) acc0 = fmaf(acc0, 2.0f, verdict); else acc1 = fmaf(acc1, 2.0f, verdict);
+                if (i == 0) after_first();
+            }
+        };
+        if constexpr (kPipelinedRecords) {
+            f16v next = pairs[0];
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const f16v f = next;
+                eight(f, g, [&] {
+                    __builtin_amdgcn_sched_barrier(0);
+                    if (g < 3) next = pairs[g + 1];
+                    __builtin_amdgcn_sched_barrier(0);
+                });
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        } else {
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const f16v f = pairs[g];
+                eight(f, g, [] {});
             }
         }
         return ((uint32_t)acc0 << 16) | (uint32_t)acc1;

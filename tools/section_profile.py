@@ -11,13 +11,15 @@ sys.path.insert(0, ROOT)
 import raytracing_amd as R
 
 spp = int(sys.argv[1]) if len(sys.argv) > 1 else 50
+big = len(sys.argv) > 2 and sys.argv[2] == "c5"          # the 20 000-sphere scene at 1920x1080 instead of the final scene at 1200x800
+W, H = (1920, 1080) if big else (1200, 800)
 rt = R.Renderer(0)
-rt.upload_scene(R.final_scene_table())
-rt.set_camera(R.final_camera(1200, 800))
+rt.upload_scene(R.scene_grid(42, 75, 19996) if big else R.final_scene_table())
+rt.set_camera(R.final_camera(W, H))
 L = R.load_library()
 buf = (C.c_ulonglong * 8)()
 L.rt_debug_section_ticks(buf, 1)
-rgb, irgb, rays, ms = rt.render(rt.params(1200, 800, spp, seed=0))
+rgb, irgb, rays, ms = rt.render(rt.params(W, H, spp, seed=0))
 L.rt_debug_section_ticks(buf, 0)
 names = ["regenerate", "ray setup+filter", "exact pass A", "exact pass B", "sparse sweep", "hit record", "scatter", "sky+store"]
 order = [0, 1, 2, 3, 4, 5, 6, 7]
