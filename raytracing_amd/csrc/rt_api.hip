@@ -5,6 +5,7 @@
 #include <cstdarg>
 #include <cstdio>
 #include <cstring>
+#include <exception>
 #include <new>
 #include <string>
 #include <thread>
@@ -51,6 +52,7 @@ int rt_create(int device_ordinal, rt_context** out)
     // RT_AMD_SAMPLE_BUFFER_KB caps the sample buffer (tests use it to run the multi-batch path on small images).
     { const char* f = getenv("RT_AMD_SAMPLE_BUFFER_KB"); const long long kb = f ? atoll(f) : 0; if (kb > 0) ctx->sample_buffer_cap = (uint64_t)kb << 10; }
     { const char* f = getenv("RT_AMD_TILE_ORDER"); ctx->tile_ordering = !(f && strcmp(f, "image") == 0); }
+    { const char* f = getenv("RT_AMD_PRIMARY"); ctx->primary_lists = !(f && strcmp(f, "sweep") == 0); }
     hipError_t e = hipSetDevice(device_ordinal);
     if (e == hipSuccess) e = hipMalloc(&ctx->d_rays, 2 * sizeof(unsigned long long));
     if (e == hipSuccess) e = hipMalloc(&ctx->d_work, sizeof(unsigned int));
@@ -70,7 +72,7 @@ void rt_destroy(rt_context* ctx)
     if (ctx->pending) (void)hipStreamSynchronize(ctx->last_stream);
     (void)hipFree(ctx->d_geom); (void)hipFree(ctx->d_mat); (void)hipFree(ctx->d_aux); (void)hipFree(ctx->d_rays); (void)hipFree(ctx->d_ppm_scratch); (void)hipFree(ctx->d_out_rgb); (void)hipFree(ctx->d_out_irgb);
     (void)hipFree(ctx->d_bvh_nodes); (void)hipFree(ctx->d_bvh_leaf); (void)hipFree(ctx->d_bvh_big);
-    (void)hipFree(ctx->d_frec); (void)hipFree(ctx->d_prec); (void)hipFree(ctx->d_force); (void)hipFree(ctx->d_samples); (void)hipFree(ctx->d_accum); (void)hipFree(ctx->d_work); (void)hipFree(ctx->d_stacks); (void)hipFree(ctx->d_staging); (void)hipFree(ctx->d_tile_cls); (void)hipFree(ctx->d_tile_order);
+    (void)hipFree(ctx->d_frec); (void)hipFree(ctx->d_prec); (void)hipFree(ctx->d_force); (void)hipFree(ctx->d_samples); (void)hipFree(ctx->d_accum); (void)hipFree(ctx->d_work); (void)hipFree(ctx->d_stacks); (void)hipFree(ctx->d_staging); (void)hipFree(ctx->d_tile_cls); (void)hipFree(ctx->d_tile_order); (void)hipFree(ctx->d_tile_lists);
     (void)hipFree(ctx->wf_ray); (void)hipFree(ctx->wf_pixsmp); (void)hipFree(ctx->wf_depth); (void)hipFree(ctx->wf_hit_t); (void)hipFree(ctx->wf_hit_idx);
     (void)hipFree(ctx->wf_stacks); (void)hipFree(ctx->wf_q[0]); (void)hipFree(ctx->wf_q[1]); (void)hipFree(ctx->wf_n);
     if (ctx->ev0) (void)hipEventDestroy(ctx->ev0);
@@ -387,9 +389,15 @@ extern "C" int rt_render_multi(rt_context** ctx, int n, const rt_params* p, floa
     std::vector<int> rc(n, RT_OK); std::vector<uint64_t> r(n, 0); std::vector<float> ms(n, 0.0f);
     std::vector<std::thread> workers;
     // one host thread per context; HIP's current device is per thread
-    for (int k = 1; k < n; ++k) workers.emplace_back([&, k] { rc[k] = render_share(ctx[k], k, n, *p, h_rgb_mean, h_irgb, &r[k], &ms[k]); });
-    rc[0] = render_share(ctx[0], 0, n, *p, h_rgb_mean, h_irgb, &r[0], &ms[0]);
+    // (no exception may cross the C boundary: a thread that cannot be started ends the call with an error once the others have joined)
+    bool started_all = true;
+    try {
+        workers.reserve((size_t)n);
+        for (int k = 1; k < n; ++k) workers.emplace_back([&, k] { rc[k] = render_share(ctx[k], k, n, *p, h_rgb_mean, h_irgb, &r[k], &ms[k]); });
+    } catch (const std::exception&) { started_all = false; }
+    if (started_all) rc[0] = render_share(ctx[0], 0, n, *p, h_rgb_mean, h_irgb, &r[0], &ms[0]);
     for (std::thread& t : workers) t.join();
+    if (!started_all) return fail(ctx[0], RT_ERR_STATE, "rt_render_multi: could not start %d host threads", n - 1);
     uint64_t total = 0;
     for (int k = 0; k < n; ++k) {
         if (rc[k] != RT_OK) { if (k != 0) ctx[0]->error = "context " + std::to_string(k) + ": " + ctx[k]->error; return rc[k]; }

@@ -30,6 +30,8 @@ struct rt_context {
     float* d_staging = nullptr;
     uint32_t* d_tile_cls = nullptr; uint32_t* d_tile_order = nullptr; size_t tile_cap = 0;   // work order of the tiles of the current call
     bool tile_ordering = true;
+    uint32_t* d_tile_lists = nullptr; size_t tile_list_cap = 0;    // per tile: the spheres its camera rays can meet (k_tile_lists)
+    bool primary_lists = true;
     // the order depends on scene, camera and the rows rendered only: it is kept for repeated calls (new seeds, more samples)
     struct TileKey { uint64_t scene_version, camera_version; int32_t width, height, band_rows, band_first, band_step; float tmin; } tile_key{};
     bool tile_key_valid = false; uint64_t scene_version = 0, camera_version = 0;

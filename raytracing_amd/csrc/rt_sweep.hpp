@@ -77,7 +77,7 @@ struct SecTimer {
 };
 #endif
 static constexpr int kChunkItems = 512;
-static constexpr int kStagingRows = 9;
+static constexpr int kStagingRows = 11;
 static constexpr int kTraceBlock = 512;         // 8 waves share one LDS copy of the scene records
 __device__ __forceinline__ float staged_load(const float* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 #ifndef RT_SUPER_WORDS

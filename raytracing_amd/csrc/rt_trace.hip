@@ -45,6 +45,7 @@ struct TraceArgs {
     const uint32_t* tile_order;           // work order of the tiles (see decode_item); may be null
     BvhScene bvh;                         // RT_MODE_BVH only
     uint16_t* stacks; uint32_t stack_stride;   // hit-index stacks in HBM: entry k of lane g at stacks[k * stack_stride + g]
+    const uint32_t* tile_lists;           // per image tile: the spheres its camera rays can meet (k_tile_lists); null: every camera ray is swept
 };
 
 // ============================================================================ work order of the tiles
@@ -137,6 +138,100 @@ __global__ void __launch_bounds__(1024) k_tile_order(const TileArgs a)
     }
 }
 
+// ============================================================================ the spheres a tile's camera rays can meet
+// The camera rays of one 8x8 tile differ only by the jitter inside their pixels and by the point of the lens they start from, so
+// they all lie in a thin cone, and only a handful of the spheres reaches into it.  k_tile_lists writes, per tile, the ascending
+// list of those spheres; k_trace then finds the closest hit of a camera ray over its tile's list with the reference's own
+// arithmetic (sphere.cpp:15-52, hittablelist.cpp:21-29) instead of a sweep over all spheres.  A sphere outside the list must be
+// one that the reference's test rejects for every ray of the tile, so the list is built to err on the side of inclusion:
+//   * rays: Camera::GetRay (camera.cpp:46-53) gives origin = o + off, direction = llc + s H + t V - o - off with
+//     off = lens_radius (dx u + dy v), dx^2 + dy^2 < 1.  The direction is affine in (s, t, dx, dy), so over the box
+//     [s0, s1] x [t0, t1] x [-1, 1]^2 its largest angle to a fixed axis is reached at one of the sixteen corners; the axis is the
+//     direction through the middle of the tile and the lens centre.  The cone gets an angular slack that covers the rounding of
+//     the float evaluation of the direction, and starts at o; the lens offset (and the rounding of the origin) is added to the
+//     radius of every sphere instead;
+//   * spheres: the float discriminant of sphere.cpp:17-25 can be positive for a line that passes up to
+//     sqrt(r^2 + 24 u (D^2 + r^2)) from the centre, D >= |origin - centre|, u = 2^-24 (see closest_hit_bvh);
+//   * the test itself runs in double precision, with a further relative 1e-5 and an absolute 1e-5 (1 + |c| + |o|) on the radius.
+// A comparison that involves a NaN counts as "may be hit".  More than 63 candidates, a cone wider than 60 degrees or a camera
+// that is not finite: no list for the tile (count 0xffffffff), its camera rays are swept like every other ray.
+constexpr int kTileListWords = 64;          // word 0: count, words 1 .. 63: sphere indices in ascending order
+constexpr uint32_t kNoTileList = 0xffffffffu;
+struct TileListArgs { const float4* geom; int n; CameraD cam; ItemGeometry ig; float tmin; uint32_t tiles; uint32_t* lists; };
+
+__global__ void __launch_bounds__(256) k_tile_lists(const TileListArgs a)
+{
+    const uint32_t tile = blockIdx.x * 4u + (threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63;
+    if (tile >= a.tiles) return;
+    uint32_t* out = a.lists + (size_t)tile * kTileListWords;
+    const int ty = (int)(tile / (uint32_t)a.ig.tiles_x), tx = (int)(tile - (uint32_t)ty * (uint32_t)a.ig.tiles_x);
+    const int i0 = tx * 8, i1 = (i0 + 8 < a.ig.width) ? i0 + 8 : a.ig.width;
+    const int r0 = ty * 8, r1 = (r0 + 7 < a.ig.owned_rows) ? r0 + 7 : a.ig.owned_rows - 1;
+    const int y0 = owned_row_to_y2(a.ig.band_rows, a.ig.band_first, a.ig.band_step, r0);
+    const int y1 = owned_row_to_y2(a.ig.band_rows, a.ig.band_first, a.ig.band_step, r1);      // y0 <= y1: the mapping is increasing
+    // u = float(i + xi) / nx with xi in [0, 1) (main.cpp:126-127) lies in [i / nx, (i + 1) / nx] up to one rounding
+    const double eps = 1e-6;
+    const double s0 = (double)i0 / (double)a.ig.width - eps, s1 = (double)i1 / (double)a.ig.width + eps;
+    const double t0 = (double)(a.ig.height - 1 - y1) / (double)a.ig.height - eps, t1 = (double)(a.ig.height - y0) / (double)a.ig.height + eps;
+    const CameraD& c = a.cam;
+    const double lr = fabs((double)c.lens_radius);
+    auto direction = [&](double s, double t, double dx, double dy, double& x, double& y, double& z) {
+        x = (double)c.llc.x + s * (double)c.horiz.x + t * (double)c.vert.x - (double)c.origin.x - lr * (dx * (double)c.u.x + dy * (double)c.v.x);
+        y = (double)c.llc.y + s * (double)c.horiz.y + t * (double)c.vert.y - (double)c.origin.y - lr * (dx * (double)c.u.y + dy * (double)c.v.y);
+        z = (double)c.llc.z + s * (double)c.horiz.z + t * (double)c.vert.z - (double)c.origin.z - lr * (dx * (double)c.u.z + dy * (double)c.v.z);
+    };
+    double ax, ay, az;
+    direction(0.5 * (s0 + s1), 0.5 * (t0 + t1), 0.0, 0.0, ax, ay, az);
+    const double alen = sqrt(ax * ax + ay * ay + az * az);
+    ax /= alen; ay /= alen; az /= alen;
+    double cos_min = 1.0, len_min = alen;
+    for (int q = 0; q < 16; ++q) {
+        double x, y, z;
+        direction((q & 1) ? s1 : s0, (q & 2) ? t1 : t0, (q & 4) ? 1.0 : -1.0, (q & 8) ? 1.0 : -1.0, x, y, z);
+        const double len = sqrt(x * x + y * y + z * z);
+        const double cs = (x * ax + y * ay + z * az) / len;
+        cos_min = cs < cos_min ? cs : cos_min;          // a NaN leaves cos_min alone and is caught through len_min below
+        len_min = !(len >= len_min) ? len : len_min;    // a NaN length ends up here
+    }
+    auto norm1 = [](V3 v) { return fabs((double)v.x) + fabs((double)v.y) + fabs((double)v.z); };
+    const double u24 = 5.9604644775390625e-08;
+    const double lens_shift = lr * (sqrt((double)dot(c.u, c.u)) + sqrt((double)dot(c.v, c.v))) * 1.0001;
+    // rounding of the float direction: four additions of terms no larger than their 1-norms, relative to the shortest direction
+    const double slack = 1e-4 + 16.0 * u24 * (norm1(c.llc) + norm1(c.horiz) + norm1(c.vert) + norm1(c.origin) + lr * (norm1(c.u) + norm1(c.v))) / len_min;
+    const double sin_min = sqrt(fmax(0.0, 1.0 - cos_min * cos_min));
+    const double cs = cos_min * cos(slack) - sin_min * sin(slack), sn = sin_min * cos(slack) + cos_min * sin(slack);   // half-angle + slack
+    const double shift = lens_shift + 8.0 * u24 * norm1(c.origin);
+    const bool usable = (alen > 0.0) && (len_min > 0.0) && (slack < 0.01) && (cs > 0.5) && (shift < 1e30);    // false for anything that is not finite
+    if (!usable) { if (lane == 0) out[0] = kNoTileList; return; }
+    const double ox = (double)c.origin.x, oy = (double)c.origin.y, oz = (double)c.origin.z;
+    const double o1 = norm1(c.origin);
+    const bool both_ways = a.tmin < 0.0f;          // roots behind the origin are accepted then
+    uint32_t count = 0;
+    for (int base = 0; base < a.n; base += 64) {
+        const int k = base + lane;
+        bool cand = false;
+        if (k < a.n) {
+            const float4 g = a.geom[k];            // (centre, r * r)
+            const double vx = (double)g.x - ox, vy = (double)g.y - oy, vz = (double)g.z - oz;
+            const double vv = vx * vx + vy * vy + vz * vz;
+            double along = vx * ax + vy * ay + vz * az;
+            const double perp = sqrt(fmax(0.0, vv - along * along));
+            if (both_ways) along = fabs(along);
+            const double r2 = (double)g.w, far = sqrt(vv) + shift;
+            const double reach = sqrt(r2 + 24.0 * u24 * (far * far + r2)) * 1.00001 + shift + 1e-5 * (1.0 + fabs((double)g.x) + fabs((double)g.y) + fabs((double)g.z) + o1);
+            // distance of the centre to the solid cone (to its surface line where the centre is beside it; behind the apex the
+            // expression is smaller than the true distance, which only adds candidates)
+            cand = !(perp * cs - along * sn > reach);
+        }
+        const unsigned long long m = __ballot(cand);
+        const uint32_t pos = count + __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
+        if (cand && pos < (uint32_t)(kTileListWords - 1)) out[1 + pos] = (uint32_t)k;
+        count += (uint32_t)__popcll(m);
+    }
+    if (lane == 0) out[0] = count <= (uint32_t)(kTileListWords - 1) ? count : kNoTileList;
+}
+
 // Six waves per SIMD (three 512-thread blocks per CU) is what the LDS budget allows and what hides the latency of the exact
 // passes; the register allocation is held to it explicitly (80 VGPRs; the allocator's own choice drifts between 77 and 96
 // with small source changes).  The hierarchy walk with the scene in LDS fits two blocks per CU only, so it keeps more registers.
@@ -148,6 +243,11 @@ __global__ void __launch_bounds__(1024) k_tile_order(const TileArgs a)
 #endif
 #define RT_TRACE_WAVES(kBvh, kLds) __attribute__((amdgpu_waves_per_eu((kBvh) && (kLds) ? 4 : RT_WAVES, (kBvh) && (kLds) ? 4 : RT_WAVES)))
 #endif
+constexpr int kUnresolved = -2;             // staging row 10: the camera ray's closest hit is not known (no list for its tile)
+#ifndef RT_LIGHT_TRIP
+#define RT_LIGHT_TRIP 16
+#endif
+constexpr int kLightTrip = RT_LIGHT_TRIP;   // lanes with a known first hit from which a trip shades them alone and skips the sweep
 template <bool kLds, bool kPlane, bool kBvh = false>
 __global__ void __launch_bounds__(kTraceBlock) RT_TRACE_WAVES(kBvh, kLds) k_trace(const TraceArgs a)
 {
@@ -232,12 +332,43 @@ __global__ void __launch_bounds__(kTraceBlock) RT_TRACE_WAVES(kBvh, kLds) k_trac
                 // Generate the camera rays of the whole chunk now, all lanes busy, into this wave's staging
                 // rows in HBM; handing an item to a lane later is then eight loads.  (Generating on demand
                 // ran this code on every trip of the main loop for the third of the lanes that had finished.)
-                for (uint32_t it = g + (uint32_t)lane; it < pool_end; it += 64u) {
+                for (uint32_t row = g; row < pool_end; row += 64u) {        // 64 items: one tile at one sample
+                    const uint32_t it = row + (uint32_t)lane;
                     uint32_t gp = 0xffffffffu, gs = 0u, gstore = 0u; int i = 0, j = 0;
                     RayD gr; gr.o = mk(0, 0, 0); gr.d = mk(0, 0, 0);
                     if (decode_item(ig, it, gp, gs, i, j, gstore)) gr = camera_ray(a.cam, gp, gs, i, j, fnx, fny, a.k0, a.k1);
                     else gp = 0xffffffffu;
                     const uint32_t slot = it - g;
+                    // The closest hit of the camera ray over the list of its tile, all lanes on the same few spheres (records as
+                    // scalar loads), in ascending sphere order with strict comparisons: HittableList::Hit's answer.
+                    float pre_t = 0.0f; int pre_k = kUnresolved;
+                    if (a.tile_lists) {
+                        const uint32_t ts = (uint32_t)__builtin_amdgcn_readfirstlane((int)(row >> 6));
+                        const uint32_t work_tile = ts / (uint32_t)a.s_count;
+                        const uint32_t tile = a.tile_order ? a.tile_order[work_tile] : work_tile;
+                        const uint32_t* list = a.tile_lists + (size_t)tile * kTileListWords;
+                        const uint32_t cnt = list[0];
+                        if (cnt != kNoTileList) {
+                            const int cand = (uint32_t)lane < cnt ? (int)list[1 + lane] : 0;
+                            const float qa = dot(gr.d, gr.d);
+                            pre_t = FLT_MAX; pre_k = -1;
+                            for (uint32_t q = 0; q < cnt; ++q) {
+                                const int k = __builtin_amdgcn_readlane(cand, (int)q);
+                                const float4 gk = a.geom[k];            // (centre, r * r)
+                                const V3 oc = gr.o - mk(gk.x, gk.y, gk.z);
+                                const float b = dot(oc, gr.d);
+                                const float cc = dot(oc, oc) - gk.w;
+                                const float desc = b * b - qa * cc;
+                                if (desc > 0.0f) {
+                                    const float sq = sqrtf(desc);
+                                    float temp = (-b - sq) / qa;
+                                    if (!(temp < pre_t && temp > a.tmin)) temp = (-b + sq) / qa;
+                                    if (temp < pre_t && temp > a.tmin) { pre_t = temp; pre_k = k; }
+                                }
+                            }
+                        }
+                    }
+                    staged[9 * kChunkItems + slot] = pre_t; staged[10 * kChunkItems + slot] = __int_as_float(pre_k);
                     staged[0 * kChunkItems + slot] = gr.o.x; staged[1 * kChunkItems + slot] = gr.o.y; staged[2 * kChunkItems + slot] = gr.o.z;
                     staged[3 * kChunkItems + slot] = gr.d.x; staged[4 * kChunkItems + slot] = gr.d.y; staged[5 * kChunkItems + slot] = gr.d.z;
                     staged[6 * kChunkItems + slot] = __uint_as_float(gp); staged[7 * kChunkItems + slot] = __uint_as_float(gs);
@@ -261,7 +392,12 @@ __global__ void __launch_bounds__(kTraceBlock) RT_TRACE_WAVES(kBvh, kLds) k_trac
                     item = __float_as_uint(staged_load(staged + 8 * kChunkItems + slot));      // where the sample is stored
                     ray.o = mk(staged_load(staged + 0 * kChunkItems + slot), staged_load(staged + 1 * kChunkItems + slot), staged_load(staged + 2 * kChunkItems + slot));
                     ray.d = mk(staged_load(staged + 3 * kChunkItems + slot), staged_load(staged + 4 * kChunkItems + slot), staged_load(staged + 5 * kChunkItems + slot));
+                    // a camera ray whose closest hit is known already: parked in this lane's filter-mask words, which only a
+                    // lane that sweeps uses; depth -1 marks it until it is shaded
+                    const float pre_t = staged_load(staged + 9 * kChunkItems + slot);
+                    const int pre_k = __float_as_int(staged_load(staged + 10 * kChunkItems + slot));
                     depth = 0;
+                    if (pre_k != kUnresolved) { mask_words[0] = __float_as_uint(pre_t); mask_words[64] = (uint32_t)pre_k; depth = -1; }
                     active = true;
                 }
             }
@@ -288,17 +424,25 @@ __global__ void __launch_bounds__(kTraceBlock) RT_TRACE_WAVES(kBvh, kLds) k_trac
             else __builtin_amdgcn_s_setprio(0);
         }
         float closest = FLT_MAX; int hit = -1;
-        const unsigned long long live = __ballot(active);
+        // Lanes that hold a camera ray with a known hit need no sweep.  When there are many of them the trip is a light one: only
+        // they are shaded (which ends their path or gives them a second ray), the free lanes are refilled, and the sweep that
+        // follows runs with nearly every lane on a ray that needs it.
+        const bool known = active && depth < 0, sweeping = active && depth >= 0;
+        const unsigned long long live = __ballot(sweeping);
+        const bool light = live == 0ull || __popcll(__ballot(known)) >= kLightTrip;
 #ifdef RT_WAVE_TIMELINE
         was_sparse = __popcll(live) <= kFewPaths && live != 0ull;
         if (t_first_sweep == 0) t_first_sweep = __builtin_amdgcn_s_memrealtime();
         else if (t_first_done == 0) t_first_done = __builtin_amdgcn_s_memrealtime();
 #endif
-        if (kBvh) { if (active) closest_hit_bvh<kLds>(ray, a.tmin, a.bvh, exact_lds, mask_words, closest, hit); }
+        if (light) {}
+        else if (kBvh) { if (sweeping) closest_hit_bvh<kLds>(ray, a.tmin, a.bvh, exact_lds, mask_words, closest, hit); }
         else if (__popcll(live) <= kFewPaths) closest_hit_few<kLds>(ray, a.tmin, sw, exact_lds, live, lane, closest, hit);
-        else if (active) closest_hit<kLds, kPlane, true>(ray, a.tmin, sw, exact_lds, mask_words, closest, hit, T);
-        rays += (uint32_t)__popcll(live); misses += (uint32_t)__popcll(__ballot(active && hit < 0));
-        if (active) {
+        else if (sweeping) closest_hit<kLds, kPlane, true>(ray, a.tmin, sw, exact_lds, mask_words, closest, hit, T);
+        if (known) { closest = __uint_as_float(mask_words[0]); hit = (int)mask_words[64]; depth = 0; }
+        const bool shade_now = known || (sweeping && !light);
+        rays += (uint32_t)__popcll(__ballot(shade_now)); misses += (uint32_t)__popcll(__ballot(shade_now && hit < 0));
+        if (shade_now) {
             T.mark(4);
             // ------------------------------------------------------------ shade (main.cpp:13-39)
             V3 sample;
@@ -402,9 +546,25 @@ int trace_prepare(rt_context* ctx, const RenderFrame& f, TracePlan* plan)
         HIP_TRY(ctx, hipMalloc(&ctx->d_staging, (lanes / 64) * kStagingRows * kChunkItems * sizeof(float)));
         ctx->stacks_lanes = lanes;
     }
+    const uint32_t n_tiles = (uint32_t)(f.Q / 64);
+    if (ctx->primary_lists) {
+        if (ctx->tile_list_cap < n_tiles) {
+            HIP_TRY(ctx, hipStreamSynchronize(st));
+            (void)hipFree(ctx->d_tile_lists); ctx->d_tile_lists = nullptr; ctx->tile_list_cap = 0;
+            HIP_TRY(ctx, hipMalloc(&ctx->d_tile_lists, (size_t)n_tiles * kTileListWords * sizeof(uint32_t)));
+            ctx->tile_list_cap = n_tiles;
+        }
+        // rebuilt with every call (it is part of the render, and cheap next to it): nothing to invalidate when scene or camera change
+        TileListArgs la{};
+        la.geom = ctx->d_geom; la.n = ctx->n; la.cam = ctx->cam; la.tmin = p->tmin;
+        la.ig.width = p->width; la.ig.height = p->height; la.ig.band_rows = p->band_rows; la.ig.band_first = p->band_first; la.ig.band_step = p->band_step;
+        la.ig.owned_rows = f.owned; la.ig.tiles_x = f.tiles_x; la.ig.Q = (uint32_t)f.Q; la.ig.s_begin = 0; la.ig.s_count = 1; la.ig.tile_order = nullptr;
+        la.tiles = n_tiles; la.lists = ctx->d_tile_lists;
+        hipLaunchKernelGGL(k_tile_lists, dim3((n_tiles + 3u) / 4u), dim3(256), 0, st, la);
+        HIP_TRY(ctx, hipGetLastError());
+    }
     t.ordered = ctx->tile_ordering;
     if (!t.ordered) return RT_OK;
-    const uint32_t n_tiles = (uint32_t)(f.Q / 64);
     if (ctx->tile_cap < n_tiles) {
         HIP_TRY(ctx, hipStreamSynchronize(st));
         (void)hipFree(ctx->d_tile_cls); (void)hipFree(ctx->d_tile_order); ctx->d_tile_cls = ctx->d_tile_order = nullptr; ctx->tile_cap = 0; ctx->tile_key_valid = false;
@@ -438,6 +598,7 @@ int trace_batch(rt_context* ctx, const RenderFrame& f, const TracePlan& t, const
     a.samples = ctx->d_samples; a.ray_counter = ctx->d_rays; a.work_counter = ctx->d_work;
     a.stacks = ctx->d_stacks; a.stack_stride = (uint32_t)ctx->stacks_lanes; a.staging = ctx->d_staging;
     a.tile_order = t.ordered ? ctx->d_tile_order : nullptr;
+    a.tile_lists = ctx->primary_lists ? ctx->d_tile_lists : nullptr;
     a.bvh.nodes = ctx->d_bvh_nodes; a.bvh.leaf_index = ctx->d_bvh_leaf; a.bvh.big = ctx->d_bvh_big; a.bvh.n_big = ctx->bvh_n_big; a.bvh.geom = ctx->d_geom;
     // small jobs take smaller chunks so that every resident wave gets several (tail balance)
     const uint64_t resident_waves = (uint64_t)ctx->num_cu * t.blocks_per_cu * (kTraceBlock / 64);
