@@ -77,7 +77,7 @@ struct SecTimer {
 };
 #endif
 static constexpr int kChunkItems = 512;
-static constexpr int kStagingRows = 11;
+static constexpr int kStagingRows = 10;
 static constexpr int kTraceBlock = 512;         // 8 waves share one LDS copy of the scene records
 __device__ __forceinline__ float staged_load(const float* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 #ifndef RT_SUPER_WORDS
@@ -564,7 +564,8 @@ __device__ __forceinline__ void closest_hit_bvh(const RayD& ray, float tmin, con
 // One level of the recursion main.cpp:13-39 for a ray whose closest hit is known.  Returns true when the
 // path has ended (sample = its radiance); otherwise ray/depth are advanced and the hit index is pushed on
 // the lane's stack (element k at stack[k * sstride]).
-template <bool kLds>
+// kNoStack: for a camera ray (depth 0) whose caller records the hit index itself; nothing is pushed and there is nothing to replay.
+template <bool kLds, bool kNoStack = false>
 __device__ __forceinline__ bool shade_step(RayD& ray, int& depth, float closest, int hit, uint32_t pix, uint32_t smp, int max_depth,
                                            KeyedUniforms& U, const float4* s_geom, const float4* s_mat, const Aux* s_aux,
                                            const float4* g_geom, const float4* g_mat, const Aux* g_aux,
@@ -583,13 +584,14 @@ __device__ __forceinline__ bool shade_step(RayD& ray, int& depth, float closest,
             V3 att; RayD out;
             U.slot(pix, smp, (uint32_t)depth + 1u);
             if (scatter(x.type, mk(m.x, m.y, m.z), m.w, ray, p, nrm, U, att, out)) {
-                stack[(size_t)depth * sstride] = (uint16_t)hit; ++depth; ray = out; done = false;
+                if (!kNoStack) stack[(size_t)depth * sstride] = (uint16_t)hit;
+                ++depth; ray = out; done = false;
             }
         }
         T.mark(6);
     } else {
         sample = sky(ray.d);
-        for (int k = depth - 1; k >= 0; --k) {
+        for (int k = kNoStack ? -1 : depth - 1; k >= 0; --k) {
             const int h = stack[(size_t)k * sstride];
             const float4 m = kLds ? s_mat[h] : g_mat[h];
             sample = mk(m.x, m.y, m.z) * sample;

@@ -243,11 +243,7 @@ __global__ void __launch_bounds__(256) k_tile_lists(const TileListArgs a)
 #endif
 #define RT_TRACE_WAVES(kBvh, kLds) __attribute__((amdgpu_waves_per_eu((kBvh) && (kLds) ? 4 : RT_WAVES, (kBvh) && (kLds) ? 4 : RT_WAVES)))
 #endif
-constexpr int kUnresolved = -2;             // staging row 10: the camera ray's closest hit is not known (no list for its tile)
-#ifndef RT_LIGHT_TRIP
-#define RT_LIGHT_TRIP 16
-#endif
-constexpr int kLightTrip = RT_LIGHT_TRIP;   // lanes with a known first hit from which a trip shades them alone and skips the sweep
+constexpr int kUnresolved = -2;             // staging row 9: the staged ray is the camera ray itself (no list for its tile), not the path's second ray
 template <bool kLds, bool kPlane, bool kBvh = false>
 __global__ void __launch_bounds__(kTraceBlock) RT_TRACE_WAVES(kBvh, kLds) k_trace(const TraceArgs a)
 {
@@ -280,7 +276,8 @@ __global__ void __launch_bounds__(kTraceBlock) RT_TRACE_WAVES(kBvh, kLds) k_trac
     int depth = 0; uint32_t item = 0, pix = 0, smp = 0;
     bool active = false;
     uint32_t rays = 0, misses = 0;             // wave-uniform: queries and sky misses of the whole wave
-    uint32_t pool_next = 0, pool_end = 0, pool_base = 0;      // wave-uniform
+    uint32_t pool_next = 0, pool_end = 0, pool_base = 0;      // wave-uniform: the staged rows not yet handed out are pool_next - pool_base .. pool_end - pool_base
+    uint32_t claim_end = 0;                                   // wave-uniform: end of the items this wave reserved last
     float* staged = a.staging + ((size_t)blockIdx.x * (kTraceBlock / 64) + wave) * (kStagingRows * kChunkItems);
     bool exhausted = false;                    // wave-uniform
     bool first_chunk = true;                   // wave-uniform
@@ -310,7 +307,7 @@ __global__ void __launch_bounds__(kTraceBlock) RT_TRACE_WAVES(kBvh, kLds) k_trac
                 // is estimated from this wave's previous reservation and one chunk per resident wave since.
                 uint32_t take = (uint32_t)a.chunk_items;
                 {
-                    const uint32_t seen = pool_end + a.resident_waves * take;
+                    const uint32_t seen = claim_end + a.resident_waves * take;
                     const uint32_t left = a.total_items > seen ? a.total_items - seen : 0u;
                     const uint32_t fair = (left / (a.resident_waves * 2u)) & ~63u;
                     if (fair < take) take = fair < a.min_chunk_items ? a.min_chunk_items : fair;
@@ -328,20 +325,22 @@ __global__ void __launch_bounds__(kTraceBlock) RT_TRACE_WAVES(kBvh, kLds) k_trac
                 }
                 if (g >= a.total_items) { exhausted = true; break; }
                 pool_next = g; pool_base = g;
-                pool_end = (a.total_items - g < take) ? a.total_items : g + take;
+                claim_end = (a.total_items - g < take) ? a.total_items : g + take;
                 // Generate the camera rays of the whole chunk now, all lanes busy, into this wave's staging
                 // rows in HBM; handing an item to a lane later is then eight loads.  (Generating on demand
                 // ran this code on every trip of the main loop for the third of the lanes that had finished.)
-                for (uint32_t row = g; row < pool_end; row += 64u) {        // 64 items: one tile at one sample
+                uint32_t kept = 0;
+                for (uint32_t row = g; row < claim_end; row += 64u) {        // 64 items: one tile at one sample
                     const uint32_t it = row + (uint32_t)lane;
                     uint32_t gp = 0xffffffffu, gs = 0u, gstore = 0u; int i = 0, j = 0;
                     RayD gr; gr.o = mk(0, 0, 0); gr.d = mk(0, 0, 0);
-                    if (decode_item(ig, it, gp, gs, i, j, gstore)) gr = camera_ray(a.cam, gp, gs, i, j, fnx, fny, a.k0, a.k1);
-                    else gp = 0xffffffffu;
-                    const uint32_t slot = it - g;
-                    // The closest hit of the camera ray over the list of its tile, all lanes on the same few spheres (records as
-                    // scalar loads), in ascending sphere order with strict comparisons: HittableList::Hit's answer.
-                    float pre_t = 0.0f; int pre_k = kUnresolved;
+                    bool keep = decode_item(ig, it, gp, gs, i, j, gstore);         // padding pixels of edge tiles are dropped here
+                    if (keep) gr = camera_ray(a.cam, gp, gs, i, j, fnx, fny, a.k0, a.k1);
+                    // The first level of Color() for the camera ray, here, where the 64 lanes hold the rays of one tile: the closest
+                    // hit over the tile's list (all lanes on the same few spheres, records as scalar loads, ascending sphere order
+                    // with strict comparisons: HittableList::Hit's answer), then the shading step.  What is staged is the SECOND
+                    // ray of the path with the index of the sphere it left; a path that ends here stores its sample and takes no lane.
+                    int first = kUnresolved;
                     if (a.tile_lists) {
                         const uint32_t ts = (uint32_t)__builtin_amdgcn_readfirstlane((int)(row >> 6));
                         const uint32_t work_tile = ts / (uint32_t)a.s_count;
@@ -351,7 +350,7 @@ __global__ void __launch_bounds__(kTraceBlock) RT_TRACE_WAVES(kBvh, kLds) k_trac
                         if (cnt != kNoTileList) {
                             const int cand = (uint32_t)lane < cnt ? (int)list[1 + lane] : 0;
                             const float qa = dot(gr.d, gr.d);
-                            pre_t = FLT_MAX; pre_k = -1;
+                            float pre_t = FLT_MAX; int pre_k = -1;
                             for (uint32_t q = 0; q < cnt; ++q) {
                                 const int k = __builtin_amdgcn_readlane(cand, (int)q);
                                 const float4 gk = a.geom[k];            // (centre, r * r)
@@ -366,14 +365,30 @@ __global__ void __launch_bounds__(kTraceBlock) RT_TRACE_WAVES(kBvh, kLds) k_trac
                                     if (temp < pre_t && temp > a.tmin) { pre_t = temp; pre_k = k; }
                                 }
                             }
+                            rays += (uint32_t)__popcll(__ballot(keep)); misses += (uint32_t)__popcll(__ballot(keep && pre_k < 0));
+                            if (keep) {
+                                int d0 = 0; V3 sample;
+                                const bool done = shade_step<kLds, true>(gr, d0, pre_t, pre_k, gp, gs, a.max_depth, U, s_geom, s_mat, s_aux, a.geom, a.mat, a.aux, nullptr, 0, sample, T);
+                                first = pre_k;
+                                if (done) {
+                                    float* o = a.samples + (size_t)gstore * 3;
+                                    o[0] = sample.x; o[1] = sample.y; o[2] = sample.z;
+                                    keep = false;
+                                }
+                            }
                         }
                     }
-                    staged[9 * kChunkItems + slot] = pre_t; staged[10 * kChunkItems + slot] = __int_as_float(pre_k);
-                    staged[0 * kChunkItems + slot] = gr.o.x; staged[1 * kChunkItems + slot] = gr.o.y; staged[2 * kChunkItems + slot] = gr.o.z;
-                    staged[3 * kChunkItems + slot] = gr.d.x; staged[4 * kChunkItems + slot] = gr.d.y; staged[5 * kChunkItems + slot] = gr.d.z;
-                    staged[6 * kChunkItems + slot] = __uint_as_float(gp); staged[7 * kChunkItems + slot] = __uint_as_float(gs);
-                    staged[8 * kChunkItems + slot] = __uint_as_float(gstore);
+                    const unsigned long long km = __ballot(keep);
+                    const uint32_t slot = kept + __builtin_amdgcn_mbcnt_hi((uint32_t)(km >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)km, 0u));
+                    kept += (uint32_t)__popcll(km);
+                    if (keep) {
+                        staged[0 * kChunkItems + slot] = gr.o.x; staged[1 * kChunkItems + slot] = gr.o.y; staged[2 * kChunkItems + slot] = gr.o.z;
+                        staged[3 * kChunkItems + slot] = gr.d.x; staged[4 * kChunkItems + slot] = gr.d.y; staged[5 * kChunkItems + slot] = gr.d.z;
+                        staged[6 * kChunkItems + slot] = __uint_as_float(gp); staged[7 * kChunkItems + slot] = __uint_as_float(gs);
+                        staged[8 * kChunkItems + slot] = __uint_as_float(gstore); staged[9 * kChunkItems + slot] = __int_as_float(first);
+                    }
                 }
+                pool_end = g + kept;        // what is handed out is the staged rows, not the items
                 // the rows are read back by other lanes of this wave: drain the stores first
                 __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -385,25 +400,19 @@ __global__ void __launch_bounds__(kTraceBlock) RT_TRACE_WAVES(kBvh, kLds) k_trac
                 const uint32_t slot = pool_next + rank - pool_base;
                 // device-scope loads: the staging rows are rewritten for every chunk, so a stale L1 line
                 // from the previous chunk must not be served
-                const uint32_t gp = __float_as_uint(staged_load(staged + 6 * kChunkItems + slot));
-                if (gp != 0xffffffffu) {            // 0xffffffff marks a padding pixel of an edge tile
-                    pix = gp;
-                    smp = __float_as_uint(staged_load(staged + 7 * kChunkItems + slot));
-                    item = __float_as_uint(staged_load(staged + 8 * kChunkItems + slot));      // where the sample is stored
-                    ray.o = mk(staged_load(staged + 0 * kChunkItems + slot), staged_load(staged + 1 * kChunkItems + slot), staged_load(staged + 2 * kChunkItems + slot));
-                    ray.d = mk(staged_load(staged + 3 * kChunkItems + slot), staged_load(staged + 4 * kChunkItems + slot), staged_load(staged + 5 * kChunkItems + slot));
-                    // a camera ray whose closest hit is known already: parked in this lane's filter-mask words, which only a
-                    // lane that sweeps uses; depth -1 marks it until it is shaded
-                    const float pre_t = staged_load(staged + 9 * kChunkItems + slot);
-                    const int pre_k = __float_as_int(staged_load(staged + 10 * kChunkItems + slot));
-                    depth = 0;
-                    if (pre_k != kUnresolved) { mask_words[0] = __float_as_uint(pre_t); mask_words[64] = (uint32_t)pre_k; depth = -1; }
-                    active = true;
-                }
+                pix = __float_as_uint(staged_load(staged + 6 * kChunkItems + slot));
+                smp = __float_as_uint(staged_load(staged + 7 * kChunkItems + slot));
+                item = __float_as_uint(staged_load(staged + 8 * kChunkItems + slot));      // where the sample is stored
+                ray.o = mk(staged_load(staged + 0 * kChunkItems + slot), staged_load(staged + 1 * kChunkItems + slot), staged_load(staged + 2 * kChunkItems + slot));
+                ray.d = mk(staged_load(staged + 3 * kChunkItems + slot), staged_load(staged + 4 * kChunkItems + slot), staged_load(staged + 5 * kChunkItems + slot));
+                // a staged second ray comes with the sphere its path left: the first entry of this lane's hit stack
+                const int first = __float_as_int(staged_load(staged + 9 * kChunkItems + slot));
+                depth = 0;
+                if (first != kUnresolved) { stack[0] = (uint16_t)first; depth = 1; }
+                active = true;
             }
             pool_next += (want < avail ? want : avail);
             need = __ballot(!active);
-            // padding pixels leave their lane idle; they are re-served next trip, which is harmless
             if (want <= avail) break;
         }
         T.mark(0);
@@ -424,25 +433,17 @@ __global__ void __launch_bounds__(kTraceBlock) RT_TRACE_WAVES(kBvh, kLds) k_trac
             else __builtin_amdgcn_s_setprio(0);
         }
         float closest = FLT_MAX; int hit = -1;
-        // Lanes that hold a camera ray with a known hit need no sweep.  When there are many of them the trip is a light one: only
-        // they are shaded (which ends their path or gives them a second ray), the free lanes are refilled, and the sweep that
-        // follows runs with nearly every lane on a ray that needs it.
-        const bool known = active && depth < 0, sweeping = active && depth >= 0;
-        const unsigned long long live = __ballot(sweeping);
-        const bool light = live == 0ull || __popcll(__ballot(known)) >= kLightTrip;
+        const unsigned long long live = __ballot(active);
 #ifdef RT_WAVE_TIMELINE
         was_sparse = __popcll(live) <= kFewPaths && live != 0ull;
         if (t_first_sweep == 0) t_first_sweep = __builtin_amdgcn_s_memrealtime();
         else if (t_first_done == 0) t_first_done = __builtin_amdgcn_s_memrealtime();
 #endif
-        if (light) {}
-        else if (kBvh) { if (sweeping) closest_hit_bvh<kLds>(ray, a.tmin, a.bvh, exact_lds, mask_words, closest, hit); }
+        if (kBvh) { if (active) closest_hit_bvh<kLds>(ray, a.tmin, a.bvh, exact_lds, mask_words, closest, hit); }
         else if (__popcll(live) <= kFewPaths) closest_hit_few<kLds>(ray, a.tmin, sw, exact_lds, live, lane, closest, hit);
-        else if (sweeping) closest_hit<kLds, kPlane, true>(ray, a.tmin, sw, exact_lds, mask_words, closest, hit, T);
-        if (known) { closest = __uint_as_float(mask_words[0]); hit = (int)mask_words[64]; depth = 0; }
-        const bool shade_now = known || (sweeping && !light);
-        rays += (uint32_t)__popcll(__ballot(shade_now)); misses += (uint32_t)__popcll(__ballot(shade_now && hit < 0));
-        if (shade_now) {
+        else if (active) closest_hit<kLds, kPlane, true>(ray, a.tmin, sw, exact_lds, mask_words, closest, hit, T);
+        rays += (uint32_t)__popcll(live); misses += (uint32_t)__popcll(__ballot(active && hit < 0));
+        if (active) {
             T.mark(4);
             // ------------------------------------------------------------ shade (main.cpp:13-39)
             V3 sample;
