@@ -139,22 +139,27 @@ __global__ void __launch_bounds__(1024) k_tile_order(const TileArgs a)
 }
 
 // ============================================================================ the spheres a tile's camera rays can meet
-// The camera rays of one 8x8 tile differ only by the jitter inside their pixels and by the point of the lens they start from, so
-// they all lie in a thin cone, and only a handful of the spheres reaches into it.  k_tile_lists writes, per tile, the ascending
-// list of those spheres; k_trace then finds the closest hit of a camera ray over its tile's list with the reference's own
-// arithmetic (sphere.cpp:15-52, hittablelist.cpp:21-29) instead of a sweep over all spheres.  A sphere outside the list must be
-// one that the reference's test rejects for every ray of the tile, so the list is built to err on the side of inclusion:
-//   * rays: Camera::GetRay (camera.cpp:46-53) gives origin = o + off, direction = llc + s H + t V - o - off with
-//     off = lens_radius (dx u + dy v), dx^2 + dy^2 < 1.  The direction is affine in (s, t, dx, dy), so over the box
-//     [s0, s1] x [t0, t1] x [-1, 1]^2 its largest angle to a fixed axis is reached at one of the sixteen corners; the axis is the
-//     direction through the middle of the tile and the lens centre.  The cone gets an angular slack that covers the rounding of
-//     the float evaluation of the direction, and starts at o; the lens offset (and the rounding of the origin) is added to the
-//     radius of every sphere instead;
-//   * spheres: the float discriminant of sphere.cpp:17-25 can be positive for a line that passes up to
-//     sqrt(r^2 + 24 u (D^2 + r^2)) from the centre, D >= |origin - centre|, u = 2^-24 (see closest_hit_bvh);
-//   * the test itself runs in double precision, with a further relative 1e-5 and an absolute 1e-5 (1 + |c| + |o|) on the radius.
-// A comparison that involves a NaN counts as "may be hit".  More than 63 candidates, a cone wider than 60 degrees or a camera
-// that is not finite: no list for the tile (count 0xffffffff), its camera rays are swept like every other ray.
+// The camera rays of one 8x8 tile differ only by the jitter inside their pixels and by the point of the lens they start from: every
+// one of them joins a point of the lens, o + off, to a point F(s, t) = llc + s H + t V of the tile's patch of the focal plane
+// (Camera::GetRay, camera.cpp:46-53: origin o + off, direction F - o - off, off = lens_radius (dx u + dy v), dx^2 + dy^2 < 1).
+// So the rays form an hourglass around the line from o through the middle Fc of the patch, and only a handful of spheres reaches
+// into it.  k_tile_lists writes, per tile, the ascending list of those spheres; k_trace then finds the closest hit of a camera ray
+// over its tile's list with the reference's own arithmetic (sphere.cpp:15-52, hittablelist.cpp:21-29) instead of a sweep over all
+// spheres.  A sphere outside the list must be one that the reference's test rejects for every ray of the tile, so the list is built
+// to err on the side of inclusion:
+//   * with |off| <= l (l = lens_radius times the largest stretch of (dx, dy) -> dx u + dy v) and |F - Fc| <= h (h = the largest
+//     distance of a corner of the patch from Fc; u = float(i + xi) / nx lies in [i / nx, (i + 1) / nx] up to one rounding, which
+//     a margin on s and t covers), the point of a ray at parameter x, (1 - x)(o + off) + x F, is within rho(x) = |1 - x| l + |x| h
+//     of the axis point A(x) = o + x (Fc - o).  A ray that meets the sphere (c, R) has |A(x) - c| <= R + rho(x) for some x (x > 0
+//     unless roots behind the origin count, tmin < 0).  With p the distance of c from the axis line, x* the parameter of its foot
+//     (moved to 0, with p = |c - o|, when it lies behind the origin), D = |Fc - o| and k = (l + h) / D, that requires
+//     p sqrt(1 - k^2) <= R + rho(x*), because rho changes by at most (l + h) per unit of x while |A(x) - c| grows like D |x - x*|;
+//   * R: the float discriminant of sphere.cpp:17-25 can be positive for a line that passes up to sqrt(r^2 + 24 u (Dc^2 + r^2))
+//     from the centre, Dc >= |origin - centre|, u = 2^-24 (see closest_hit_bvh);
+//   * the test runs in double precision; the rounding of the float ray (four additions per component of the direction, one of
+//     the origin) moves its points by less than the absolute margin 1e-5 (1 + |c| + |o| + what the direction's terms add up to).
+// A comparison that involves a NaN counts as "may be hit".  More than 63 candidates, k >= 1/2 or a camera that is not finite:
+// no list for the tile (count 0xffffffff), its camera rays are swept like every other ray.
 constexpr int kTileListWords = 64;          // word 0: count, words 1 .. 63: sphere indices in ascending order
 constexpr uint32_t kNoTileList = 0xffffffffu;
 struct TileListArgs { const float4* geom; int n; CameraD cam; ItemGeometry ig; float tmin; uint32_t tiles; uint32_t* lists; };
@@ -175,36 +180,33 @@ __global__ void __launch_bounds__(256) k_tile_lists(const TileListArgs a)
     const double s0 = (double)i0 / (double)a.ig.width - eps, s1 = (double)i1 / (double)a.ig.width + eps;
     const double t0 = (double)(a.ig.height - 1 - y1) / (double)a.ig.height - eps, t1 = (double)(a.ig.height - y0) / (double)a.ig.height + eps;
     const CameraD& c = a.cam;
-    const double lr = fabs((double)c.lens_radius);
-    auto direction = [&](double s, double t, double dx, double dy, double& x, double& y, double& z) {
-        x = (double)c.llc.x + s * (double)c.horiz.x + t * (double)c.vert.x - (double)c.origin.x - lr * (dx * (double)c.u.x + dy * (double)c.v.x);
-        y = (double)c.llc.y + s * (double)c.horiz.y + t * (double)c.vert.y - (double)c.origin.y - lr * (dx * (double)c.u.y + dy * (double)c.v.y);
-        z = (double)c.llc.z + s * (double)c.horiz.z + t * (double)c.vert.z - (double)c.origin.z - lr * (dx * (double)c.u.z + dy * (double)c.v.z);
+    auto focal = [&](double s, double t, double& x, double& y, double& z) {
+        x = (double)c.llc.x + s * (double)c.horiz.x + t * (double)c.vert.x;
+        y = (double)c.llc.y + s * (double)c.horiz.y + t * (double)c.vert.y;
+        z = (double)c.llc.z + s * (double)c.horiz.z + t * (double)c.vert.z;
     };
-    double ax, ay, az;
-    direction(0.5 * (s0 + s1), 0.5 * (t0 + t1), 0.0, 0.0, ax, ay, az);
-    const double alen = sqrt(ax * ax + ay * ay + az * az);
-    ax /= alen; ay /= alen; az /= alen;
-    double cos_min = 1.0, len_min = alen;
-    for (int q = 0; q < 16; ++q) {
+    const double ox = (double)c.origin.x, oy = (double)c.origin.y, oz = (double)c.origin.z;
+    double fx, fy, fz;
+    focal(0.5 * (s0 + s1), 0.5 * (t0 + t1), fx, fy, fz);
+    double h = 0.0;
+    for (int q = 0; q < 4; ++q) {
         double x, y, z;
-        direction((q & 1) ? s1 : s0, (q & 2) ? t1 : t0, (q & 4) ? 1.0 : -1.0, (q & 8) ? 1.0 : -1.0, x, y, z);
-        const double len = sqrt(x * x + y * y + z * z);
-        const double cs = (x * ax + y * ay + z * az) / len;
-        cos_min = cs < cos_min ? cs : cos_min;          // a NaN leaves cos_min alone and is caught through len_min below
-        len_min = !(len >= len_min) ? len : len_min;    // a NaN length ends up here
+        focal((q & 1) ? s1 : s0, (q & 2) ? t1 : t0, x, y, z);
+        const double d = sqrt((x - fx) * (x - fx) + (y - fy) * (y - fy) + (z - fz) * (z - fz));
+        h = !(d <= h) ? d : h;                  // a NaN ends up here
     }
+    double wx = fx - ox, wy = fy - oy, wz = fz - oz;
+    const double D = sqrt(wx * wx + wy * wy + wz * wz);
+    wx /= D; wy /= D; wz /= D;
+    const double uu = (double)dot(c.u, c.u), vv2 = (double)dot(c.v, c.v), uv = fabs((double)dot(c.u, c.v));
+    const double l = fabs((double)c.lens_radius) * sqrt((uu > vv2 ? uu : vv2) + uv) * 1.0001;
+    const double kappa = (l + h) / D;
     auto norm1 = [](V3 v) { return fabs((double)v.x) + fabs((double)v.y) + fabs((double)v.z); };
     const double u24 = 5.9604644775390625e-08;
-    const double lens_shift = lr * (sqrt((double)dot(c.u, c.u)) + sqrt((double)dot(c.v, c.v))) * 1.0001;
-    // rounding of the float direction: four additions of terms no larger than their 1-norms, relative to the shortest direction
-    const double slack = 1e-4 + 16.0 * u24 * (norm1(c.llc) + norm1(c.horiz) + norm1(c.vert) + norm1(c.origin) + lr * (norm1(c.u) + norm1(c.v))) / len_min;
-    const double sin_min = sqrt(fmax(0.0, 1.0 - cos_min * cos_min));
-    const double cs = cos_min * cos(slack) - sin_min * sin(slack), sn = sin_min * cos(slack) + cos_min * sin(slack);   // half-angle + slack
-    const double shift = lens_shift + 8.0 * u24 * norm1(c.origin);
-    const bool usable = (alen > 0.0) && (len_min > 0.0) && (slack < 0.01) && (cs > 0.5) && (shift < 1e30);    // false for anything that is not finite
+    const double terms = norm1(c.llc) + norm1(c.horiz) + norm1(c.vert) + norm1(c.origin) + fabs((double)c.lens_radius) * (norm1(c.u) + norm1(c.v));
+    const bool usable = (D > 0.0) && (kappa < 0.5) && (terms < 1e30);      // false for anything that is not finite
     if (!usable) { if (lane == 0) out[0] = kNoTileList; return; }
-    const double ox = (double)c.origin.x, oy = (double)c.origin.y, oz = (double)c.origin.z;
+    const double shrink = sqrt(1.0 - kappa * kappa);
     const double o1 = norm1(c.origin);
     const bool both_ways = a.tmin < 0.0f;          // roots behind the origin are accepted then
     uint32_t count = 0;
@@ -215,14 +217,14 @@ __global__ void __launch_bounds__(256) k_tile_lists(const TileListArgs a)
             const float4 g = a.geom[k];            // (centre, r * r)
             const double vx = (double)g.x - ox, vy = (double)g.y - oy, vz = (double)g.z - oz;
             const double vv = vx * vx + vy * vy + vz * vz;
-            double along = vx * ax + vy * ay + vz * az;
-            const double perp = sqrt(fmax(0.0, vv - along * along));
-            if (both_ways) along = fabs(along);
-            const double r2 = (double)g.w, far = sqrt(vv) + shift;
-            const double reach = sqrt(r2 + 24.0 * u24 * (far * far + r2)) * 1.00001 + shift + 1e-5 * (1.0 + fabs((double)g.x) + fabs((double)g.y) + fabs((double)g.z) + o1);
-            // distance of the centre to the solid cone (to its surface line where the centre is beside it; behind the apex the
-            // expression is smaller than the true distance, which only adds candidates)
-            cand = !(perp * cs - along * sn > reach);
+            double along = vx * wx + vy * wy + vz * wz;
+            double p = sqrt(fmax(0.0, vv - along * along));
+            if (!both_ways && along < 0.0) { p = sqrt(vv); along = 0.0; }
+            const double x = along / D;
+            const double rho = fabs(1.0 - x) * l + fabs(x) * h;
+            const double r2 = (double)g.w, far = sqrt(vv) + l;
+            const double reach = sqrt(r2 + 24.0 * u24 * (far * far + r2)) * 1.00001 + 1e-5 * (1.0 + fabs((double)g.x) + fabs((double)g.y) + fabs((double)g.z) + o1 + terms * (1.0 + fabs(x)));
+            cand = !(p * shrink > reach + rho);
         }
         const unsigned long long m = __ballot(cand);
         const uint32_t pos = count + __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
@@ -330,6 +332,8 @@ __global__ void __launch_bounds__(kTraceBlock) RT_TRACE_WAVES(kBvh, kLds) k_trac
                 // rows in HBM; handing an item to a lane later is then eight loads.  (Generating on demand
                 // ran this code on every trip of the main loop for the third of the lanes that had finished.)
                 uint32_t kept = 0;
+                // the list of the tile the current row belongs to: lane q holds candidate q (index and exact record), fetched when the tile changes
+                uint32_t list_tile = 0xffffffffu, cnt = kNoTileList; int cand = 0; float4 crec = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
                 for (uint32_t row = g; row < claim_end; row += 64u) {        // 64 items: one tile at one sample
                     const uint32_t it = row + (uint32_t)lane;
                     uint32_t gp = 0xffffffffu, gs = 0u, gstore = 0u; int i = 0, j = 0;
@@ -344,19 +348,28 @@ __global__ void __launch_bounds__(kTraceBlock) RT_TRACE_WAVES(kBvh, kLds) k_trac
                     if (a.tile_lists) {
                         const uint32_t ts = (uint32_t)__builtin_amdgcn_readfirstlane((int)(row >> 6));
                         const uint32_t work_tile = ts / (uint32_t)a.s_count;
-                        const uint32_t tile = a.tile_order ? a.tile_order[work_tile] : work_tile;
-                        const uint32_t* list = a.tile_lists + (size_t)tile * kTileListWords;
-                        const uint32_t cnt = list[0];
+                        if (work_tile != list_tile) {
+                            list_tile = work_tile;
+                            const uint32_t tile = a.tile_order ? a.tile_order[work_tile] : work_tile;
+                            const uint32_t* list = a.tile_lists + (size_t)tile * kTileListWords;
+                            cnt = (uint32_t)__builtin_amdgcn_readfirstlane((int)list[0]);
+                            if (cnt != kNoTileList) {
+                                cand = (uint32_t)lane < cnt ? (int)list[1 + lane] : 0;
+                                crec = a.geom[cand];            // (centre, r * r)
+                            }
+                        }
                         if (cnt != kNoTileList) {
-                            const int cand = (uint32_t)lane < cnt ? (int)list[1 + lane] : 0;
                             const float qa = dot(gr.d, gr.d);
                             float pre_t = FLT_MAX; int pre_k = -1;
                             for (uint32_t q = 0; q < cnt; ++q) {
                                 const int k = __builtin_amdgcn_readlane(cand, (int)q);
-                                const float4 gk = a.geom[k];            // (centre, r * r)
-                                const V3 oc = gr.o - mk(gk.x, gk.y, gk.z);
+                                const V3 cq = mk(__builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, crec.x), (int)q)),
+                                                 __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, crec.y), (int)q)),
+                                                 __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, crec.z), (int)q)));
+                                const float r2 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, crec.w), (int)q));
+                                const V3 oc = gr.o - cq;
                                 const float b = dot(oc, gr.d);
-                                const float cc = dot(oc, oc) - gk.w;
+                                const float cc = dot(oc, oc) - r2;
                                 const float desc = b * b - qa * cc;
                                 if (desc > 0.0f) {
                                     const float sq = sqrtf(desc);
@@ -368,7 +381,8 @@ __global__ void __launch_bounds__(kTraceBlock) RT_TRACE_WAVES(kBvh, kLds) k_trac
                             rays += (uint32_t)__popcll(__ballot(keep)); misses += (uint32_t)__popcll(__ballot(keep && pre_k < 0));
                             if (keep) {
                                 int d0 = 0; V3 sample;
-                                const bool done = shade_step<kLds, true>(gr, d0, pre_t, pre_k, gp, gs, a.max_depth, U, s_geom, s_mat, s_aux, a.geom, a.mat, a.aux, nullptr, 0, sample, T);
+                                SecTimer untimed;            // (diagnostic build: the staging phase is timed as a whole)
+                                const bool done = shade_step<kLds, true>(gr, d0, pre_t, pre_k, gp, gs, a.max_depth, U, s_geom, s_mat, s_aux, a.geom, a.mat, a.aux, nullptr, 0, sample, untimed);
                                 first = pre_k;
                                 if (done) {
                                     float* o = a.samples + (size_t)gstore * 3;
