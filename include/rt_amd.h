@@ -218,6 +218,13 @@ int rt_test_get_ray(rt_context *ctx, int n, const rt_camera_pod *cam, const floa
 int rt_test_helpers(rt_context *ctx, int n, const float *v, const float *normal, const float *ni_over_nt,
                     const float *cosine, const float *ref_idx, float *reflected, int32_t *refract_ok,
                     float *refracted, float *schlick);
+/* The candidate lists that the default render path builds for the camera rays of the rows `p` selects, copied to the host: per
+ * 8x8 pixel tile (row-major over the owned rows) 64 words, word 0 = number of spheres (0xffffffff: no list, the tile's camera rays
+ * are swept over all spheres), words 1.. = their indices in ascending order.  The first level of Color() (main.cpp:13-39) for a
+ * camera ray searches only its tile's list, so every sphere HittableList::Hit (hittablelist.cpp:13-31) could report for a ray of the
+ * tile (Camera::GetRay, camera.cpp:46-53, over the tile's pixels, all jitters and the whole lens) has to be on it.  *tiles receives
+ * the number of tiles; RT_ERR_TOO_LARGE when capacity_words < 64 * *tiles. */
+int rt_test_tile_lists(rt_context *ctx, const rt_params *p, uint32_t *lists, int64_t capacity_words, int64_t *tiles);
 /* Philox4x32-10 blocks: ctr[4n], key[2] -> out[4n]. */
 int rt_test_philox(rt_context *ctx, int n, const uint32_t *ctr, const uint32_t *key, uint32_t *out);
 

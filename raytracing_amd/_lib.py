@@ -15,7 +15,7 @@ LAMBERTIAN, METAL, DIELECTRIC = 0, 1, 2
 EXPORTS = ["rt_device_count", "rt_create", "rt_destroy", "rt_last_error", "rt_upload_scene", "rt_set_camera",
            "rt_owned_rows", "rt_owned_pixels", "rt_render_device", "rt_render_stats", "rt_render_counters", "rt_render", "rt_render_multi",
            "rt_scene_grid", "rt_build_hierarchy", "rt_format_ppm", "rt_write_ppm", "rt_write_ppm_binary", "rt_encode_ppm_device", "rt_encode_ppm_device_noalloc", "rt_write_ppm_device", "rt_test_sphere_hit", "rt_test_scatter", "rt_test_get_ray",
-           "rt_test_helpers", "rt_test_philox"]
+           "rt_test_helpers", "rt_test_tile_lists", "rt_test_philox"]
 
 
 class RtError(RuntimeError):
@@ -108,6 +108,7 @@ def load_library():
     L.rt_test_scatter.argtypes = [vp, C.c_int, ip, fp, fp, fp, fp, fp, fp, ip, C.c_int, ip, fp, fp, fp, ip]
     L.rt_test_get_ray.argtypes = [vp, C.c_int, C.POINTER(CameraPod), fp, fp, fp, fp, fp]
     L.rt_test_helpers.argtypes = [vp, C.c_int, fp, fp, fp, fp, fp, fp, ip, fp, fp]
+    L.rt_test_tile_lists.argtypes = [vp, C.POINTER(Params), C.POINTER(C.c_uint32), C.c_int64, C.POINTER(C.c_int64)]
     L.rt_test_philox.argtypes = [vp, C.c_int, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]
     _lib = L
     return L
@@ -306,6 +307,15 @@ class Renderer:
         ok = np.zeros(n, np.int32)
         self._check(self._L.rt_test_helpers(self._ctx, n, _fp(v_), _fp(n_), _fp(a), _fp(b), _fp(c), _fp(refl), _ip(ok), _fp(refr), _fp(sch)))
         return refl.reshape(n, 3), ok, refr.reshape(n, 3), sch
+
+    def test_tile_lists(self, p):
+        """Candidate lists of the camera rays, per 8x8 tile of the owned rows: (counts[tiles] (-1: no list), lists[tiles, 63])."""
+        tiles = ((p.width + 7) // 8) * ((self.owned_rows(p) + 7) // 8)
+        words = np.zeros(max(tiles, 1) * 64, dtype=np.uint32)
+        got = C.c_int64(0)
+        self._check(self._L.rt_test_tile_lists(self._ctx, C.byref(p), words.ctypes.data_as(C.POINTER(C.c_uint32)), words.size, C.byref(got)))
+        words = words[:got.value * 64].reshape(got.value, 64)
+        return np.where(words[:, 0] == 0xffffffff, -1, words[:, 0].astype(np.int64)), words[:, 1:]
 
     def test_philox(self, ctr, key):
         c = np.ascontiguousarray(ctr, dtype=np.uint32).reshape(-1)

@@ -532,6 +532,46 @@ TraceKernel trace_kernel(const TracePlan& t)
 }
 }  // namespace
 
+// The candidate lists of every tile of the rows `p` selects, into ctx->d_tile_lists.  Rebuilt with every call (it is part of the
+// render, and cheap next to it): nothing to invalidate when scene or camera change.
+static int build_tile_lists(rt_context* ctx, const rt_params* p, int owned, hipStream_t st)
+{
+    const int tiles_x = (p->width + 7) / 8;
+    const uint32_t n_tiles = (uint32_t)tiles_x * (uint32_t)((owned + 7) / 8);
+    if (ctx->tile_list_cap < n_tiles) {
+        HIP_TRY(ctx, hipStreamSynchronize(st));
+        (void)hipFree(ctx->d_tile_lists); ctx->d_tile_lists = nullptr; ctx->tile_list_cap = 0;
+        HIP_TRY(ctx, hipMalloc(&ctx->d_tile_lists, (size_t)n_tiles * kTileListWords * sizeof(uint32_t)));
+        ctx->tile_list_cap = n_tiles;
+    }
+    TileListArgs la{};
+    la.geom = ctx->d_geom; la.n = ctx->n; la.cam = ctx->cam; la.tmin = p->tmin;
+    la.ig.width = p->width; la.ig.height = p->height; la.ig.band_rows = p->band_rows; la.ig.band_first = p->band_first; la.ig.band_step = p->band_step;
+    la.ig.owned_rows = owned; la.ig.tiles_x = tiles_x; la.ig.Q = n_tiles * 64u; la.ig.s_begin = 0; la.ig.s_count = 1; la.ig.tile_order = nullptr;
+    la.tiles = n_tiles; la.lists = ctx->d_tile_lists;
+    hipLaunchKernelGGL(k_tile_lists, dim3((n_tiles + 3u) / 4u), dim3(256), 0, st, la);
+    HIP_TRY(ctx, hipGetLastError());
+    return RT_OK;
+}
+
+extern "C" int rt_test_tile_lists(rt_context* ctx, const rt_params* p, uint32_t* lists, int64_t capacity_words, int64_t* tiles)
+{
+    if (!ctx) return fail(nullptr, RT_ERR_INVALID, "rt_test_tile_lists: null context");
+    if (!params_ok(p) || !tiles) return fail(ctx, RT_ERR_INVALID, "rt_test_tile_lists: invalid parameters");
+    if (!ctx->n || !ctx->have_camera) return fail(ctx, RT_ERR_STATE, "rt_test_tile_lists: no scene or no camera");
+    const int64_t owned = rt_owned_rows(p);
+    *tiles = (int64_t)((p->width + 7) / 8) * ((owned + 7) / 8);
+    if (*tiles == 0) return RT_OK;
+    if (*tiles > (1ll << 24)) return fail(ctx, RT_ERR_TOO_LARGE, "rt_test_tile_lists: %lld tiles", (long long)*tiles);
+    if (!lists || capacity_words < *tiles * kTileListWords) return fail(ctx, RT_ERR_TOO_LARGE, "rt_test_tile_lists: %lld words needed", (long long)(*tiles * kTileListWords));
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    const int rc = build_tile_lists(ctx, p, (int)owned, nullptr);
+    if (rc != RT_OK) return rc;
+    HIP_TRY(ctx, hipStreamSynchronize(nullptr));
+    HIP_TRY(ctx, hipMemcpy(lists, ctx->d_tile_lists, (size_t)*tiles * kTileListWords * sizeof(uint32_t), hipMemcpyDeviceToHost));
+    return RT_OK;
+}
+
 // Settles what every batch of the call shares: which instantiation of k_trace runs and how many of its blocks fit a CU,
 // the per-lane hit stacks and per-wave staging rows for that many resident waves, and the work order of the tiles.
 int trace_prepare(rt_context* ctx, const RenderFrame& f, TracePlan* plan)
@@ -562,22 +602,7 @@ int trace_prepare(rt_context* ctx, const RenderFrame& f, TracePlan* plan)
         ctx->stacks_lanes = lanes;
     }
     const uint32_t n_tiles = (uint32_t)(f.Q / 64);
-    if (ctx->primary_lists) {
-        if (ctx->tile_list_cap < n_tiles) {
-            HIP_TRY(ctx, hipStreamSynchronize(st));
-            (void)hipFree(ctx->d_tile_lists); ctx->d_tile_lists = nullptr; ctx->tile_list_cap = 0;
-            HIP_TRY(ctx, hipMalloc(&ctx->d_tile_lists, (size_t)n_tiles * kTileListWords * sizeof(uint32_t)));
-            ctx->tile_list_cap = n_tiles;
-        }
-        // rebuilt with every call (it is part of the render, and cheap next to it): nothing to invalidate when scene or camera change
-        TileListArgs la{};
-        la.geom = ctx->d_geom; la.n = ctx->n; la.cam = ctx->cam; la.tmin = p->tmin;
-        la.ig.width = p->width; la.ig.height = p->height; la.ig.band_rows = p->band_rows; la.ig.band_first = p->band_first; la.ig.band_step = p->band_step;
-        la.ig.owned_rows = f.owned; la.ig.tiles_x = f.tiles_x; la.ig.Q = (uint32_t)f.Q; la.ig.s_begin = 0; la.ig.s_count = 1; la.ig.tile_order = nullptr;
-        la.tiles = n_tiles; la.lists = ctx->d_tile_lists;
-        hipLaunchKernelGGL(k_tile_lists, dim3((n_tiles + 3u) / 4u), dim3(256), 0, st, la);
-        HIP_TRY(ctx, hipGetLastError());
-    }
+    if (ctx->primary_lists) { const int rc = build_tile_lists(ctx, p, f.owned, st); if (rc != RT_OK) return rc; }
     t.ordered = ctx->tile_ordering;
     if (!t.ordered) return RT_OK;
     if (ctx->tile_cap < n_tiles) {

@@ -491,6 +491,92 @@ def test_random_scenes_match_oracle_in_all_modes(rt):
             assert np.array_equal(irgb, wq), (case, n, mode)
 
 
+def test_camera_rays_through_tile_lists_equal_the_full_sweep(rt, monkeypatch):
+    """By default the first level of Color() (main.cpp:13-39) for a camera ray is worked out against the list of spheres that the
+    rays of its 8x8 tile can reach; RT_AMD_PRIMARY=sweep (read when a context is created) sweeps camera rays like every other
+    ray.  The list has to contain every sphere the reference's test could accept, so both contexts, and the per-pixel kernel
+    that knows neither lists nor filters, must agree bit for bit where the list is hardest to get right: wide lenses focused
+    close, a camera inside spheres (hollow ones too), roots behind the origin (negative tmin), a skewed camera record, rows
+    dealt out one by one over three ranks (a tile then spans rows far apart), more candidates than a list holds, and a camera
+    that is not finite (no list; such rays hit nothing)."""
+    monkeypatch.setenv("RT_AMD_PRIMARY", "sweep")
+    swept = R.Renderer(0)
+    monkeypatch.delenv("RT_AMD_PRIMARY")
+    rng = np.random.default_rng(77)
+    W, H, S = 104, 60, 2
+
+    def pod_of(look_from, look_at, vfov, aperture, focus):
+        ocam = O.make_camera(look_from, look_at, (0.0, 1.0, 0.0), vfov, np.float32(W) / np.float32(H), aperture, focus)
+        pod = R.CameraPod()
+        for dst, src in (("origin", "origin"), ("lower_left_corner", "llc"), ("horizontal", "horiz"), ("vertical", "vert"), ("u", "u"), ("v", "v"), ("w", "w")):
+            vec = getattr(ocam, src)
+            getattr(pod, dst)[:] = [vec.x, vec.y, vec.z]
+        pod.lens_radius = ocam.lens_radius
+        return pod
+
+    cases = []
+    for k in range(6):       # wide lenses, close focus, spheres down to the lens
+        cases.append((_random_scene(rng, int(rng.choice([40, 300]))), pod_of(rng.uniform(-3, 3, 3), rng.uniform(-1, 1, 3), float(rng.choice([25.0, 70.0])), float(rng.choice([0.5, 2.0, 4.0])), float(rng.uniform(0.4, 5.0))), {}))
+    inside = _random_scene(rng, 60)
+    inside[0] = [0.2, 0.1, -0.3, 2.5, R.DIELECTRIC, 1.0, 1.0, 1.0, 1.5]           # the camera sits inside this one ...
+    inside[1] = [0.2, 0.1, -0.3, -2.3, R.DIELECTRIC, 1.0, 1.0, 1.0, 1.5]          # ... and inside its hollow twin
+    cases.append((inside, pod_of((0.0, 0.0, 0.0), (1.0, 0.2, -1.0), 60.0, 0.2, 2.0), {}))
+    cases.append((_random_scene(rng, 120), pod_of((2.0, 1.0, 2.0), (0.0, 0.0, 0.0), 50.0, 0.3, 3.0), {"tmin": -0.75}))      # roots behind the origin count
+    cases.append((_random_scene(rng, 120), pod_of((2.0, 1.0, 2.0), (0.0, 0.0, 0.0), 50.0, 0.0, 3.0), {"tmin": -1e30}))
+    skew = pod_of((3.0, 1.5, 2.0), (0.0, 0.3, 0.0), 40.0, 0.6, 3.5)
+    skew.u[:] = [1.7 * skew.u[0] + 0.4 * skew.v[0], 1.7 * skew.u[1] + 0.4 * skew.v[1], 1.7 * skew.u[2] + 0.4 * skew.v[2]]          # neither unit nor orthogonal
+    skew.vertical[:] = [skew.vertical[0] + 0.3, skew.vertical[1], skew.vertical[2] - 0.2]
+    cases.append((_random_scene(rng, 200), skew, {}))
+    cases.append((_random_scene(rng, 200), pod_of((3.0, 1.5, 2.0), (0.0, 0.3, 0.0), 40.0, 0.3, 3.5), {"band_rows": 1, "band_first": 1, "band_step": 3}))
+    crowd = _random_scene(rng, 3000)
+    crowd[:, 0:3] = rng.uniform(-0.6, 0.6, size=(3000, 3)); crowd[:, 3] = 0.05                                                      # hundreds of spheres behind every tile
+    cases.append((np.asarray(crowd, dtype=np.float32).astype(np.float64), pod_of((0.0, 0.0, 4.0), (0.0, 0.0, 0.0), 20.0, 0.1, 4.0), {}))
+    broken = pod_of((3.0, 1.5, 2.0), (0.0, 0.3, 0.0), 40.0, 0.3, 3.5)
+    broken.horizontal[1] = float("nan")
+    cases.append((_random_scene(rng, 50), broken, {}))
+    far = pod_of((3.0e4, 1.5e4, 2.0e4), (0.0, 0.0, 0.0), 0.02, 0.0, 4.0e4)          # the float ray's direction is coarse here
+    cases.append((_random_scene(rng, 80), far, {}))
+
+    listed = []
+    for case, (table, pod, extra) in enumerate(cases):
+        results = []
+        for r in (rt, swept):
+            r.upload_scene(table)
+            r.set_camera(pod)
+            p = r.params(W, H, S, seed=300 + case, **{k: v for k, v in extra.items() if k != "tmin"})
+            if "tmin" in extra:
+                p.tmin = extra["tmin"]
+            results.append(r.render(p)[:3] + (r.counters(),))
+            if r is rt:
+                counts, lists = rt.test_tile_lists(p)
+                listed.append(float(np.mean(counts >= 0)))
+                for c, row in zip(counts, lists):
+                    assert c < 0 or (np.all(np.diff(row[:c].astype(np.int64)) > 0) and (c == 0 or row[c - 1] < len(table))), case       # ascending, in range
+                p.mode = R.MODE_PIXEL
+                results.append(r.render(p)[:3] + (r.counters(),))
+        base = results[0]
+        for other in results[1:]:
+            assert other[2] == base[2], case
+            assert other[3] == base[3], case
+            assert np.array_equal(other[0].view(np.uint32), base[0].view(np.uint32)), case
+            assert np.array_equal(other[1], base[1]), case
+    swept.close()
+    # the cases are about lists, so most of their tiles must have one: all but the crowd, the camera that is not finite and the far one
+    shares = [round(f, 2) for f in listed]
+    assert sum(f > 0.9 for f in listed[:11]) >= 9 and min(listed[:11]) > 0.1, shares       # (a four-unit lens over 300 spheres overflows most lists)
+    assert listed[11] < 0.8 and listed[12] == 0.0, shares
+
+
+def test_tile_lists_of_the_final_scene_are_short(rt):
+    """The benchmark's scene and camera (main.cpp:41-83, 111-116) at 1200x800: every tile has a list, and a list holds a few
+    spheres of the 487 (the ground sphere is on most)."""
+    rt.upload_scene(R.final_scene_table())
+    rt.set_camera(R.final_camera(1200, 800))
+    counts, lists = rt.test_tile_lists(rt.params(1200, 800, 1))
+    assert counts.shape == (150 * 100,) and counts.min() >= 0
+    assert counts.mean() < 8.0 and counts.max() <= 40, (counts.mean(), counts.max())
+
+
 def test_full_size_rows_match_the_reference_build(rt):
     """Rows of the 1200x800 image (the size the benchmark is quoted on) rendered by the reference's own code -- the pinned build
     oracle/_ref/ref_harness, compiled from the reference's sources where they lie -- on the keyed stream, against every kernel
