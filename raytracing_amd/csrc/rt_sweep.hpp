@@ -76,10 +76,22 @@ struct SecTimer {
     __device__ __forceinline__ void flush(int) {}
 };
 #endif
-static constexpr int kChunkItems = 512;
-static constexpr int kStagingRows = 10;
+#ifndef RT_CHUNK_ITEMS
+#define RT_CHUNK_ITEMS 512
+#endif
+static constexpr int kChunkItems = RT_CHUNK_ITEMS;
+static constexpr int kStagedFloats = 16;       // one staged ray: 64 bytes (origin, direction, pixel key, sample, sample-buffer slot, first sphere, padding)
 static constexpr int kTraceBlock = 512;         // 8 waves share one LDS copy of the scene records
-__device__ __forceinline__ float staged_load(const float* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+// A staged ray is read back by another lane of the wave that wrote it, and its slot is rewritten for every chunk: the loads are
+// device-scope ones (sc1), so that a line of the previous chunk still in this CU's L1 is not served.  Three loads off one address
+// and one wait for the lot.
+typedef float v4f __attribute__((ext_vector_type(4)));
+typedef float v2f __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ void staged_read(const float* rec, v4f& a, v4f& b, v2f& c)
+{
+    asm volatile("global_load_dwordx4 %0, %3, off sc1\n\tglobal_load_dwordx4 %1, %3, off offset:16 sc1\n\tglobal_load_dwordx2 %2, %3, off offset:32 sc1\n\ts_waitcnt vmcnt(0)"
+                 : "=&v"(a), "=&v"(b), "=&v"(c) : "v"(rec) : "memory");
+}
 #ifndef RT_SUPER_WORDS
 #define RT_SUPER_WORDS 16
 #endif

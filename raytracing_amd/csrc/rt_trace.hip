@@ -41,7 +41,7 @@ struct TraceArgs {
     float* samples;                       // [total_items][3]
     unsigned long long* ray_counter;
     unsigned int* work_counter;
-    float* staging;                       // per wave: kStagingRows rows (o, d, pixel, sample, sample-buffer slot) of kChunkItems pre-generated camera rays
+    float* staging;                       // per wave: kChunkItems staged rays of kStagedFloats floats (see the hand-out in k_trace)
     const uint32_t* tile_order;           // work order of the tiles (see decode_item); may be null
     BvhScene bvh;                         // RT_MODE_BVH only
     uint16_t* stacks; uint32_t stack_stride;   // hit-index stacks in HBM: entry k of lane g at stacks[k * stack_stride + g]
@@ -280,7 +280,7 @@ __global__ void __launch_bounds__(kTraceBlock) RT_TRACE_WAVES(kBvh, kLds) k_trac
     uint32_t rays = 0, misses = 0;             // wave-uniform: queries and sky misses of the whole wave
     uint32_t pool_next = 0, pool_end = 0, pool_base = 0;      // wave-uniform: the staged rows not yet handed out are pool_next - pool_base .. pool_end - pool_base
     uint32_t claim_end = 0;                                   // wave-uniform: end of the items this wave reserved last
-    float* staged = a.staging + ((size_t)blockIdx.x * (kTraceBlock / 64) + wave) * (kStagingRows * kChunkItems);
+    float* staged = a.staging + ((size_t)blockIdx.x * (kTraceBlock / 64) + wave) * (kStagedFloats * kChunkItems);
     bool exhausted = false;                    // wave-uniform
     bool first_chunk = true;                   // wave-uniform
     const float fnx = (float)a.width, fny = (float)a.height;
@@ -329,7 +329,7 @@ __global__ void __launch_bounds__(kTraceBlock) RT_TRACE_WAVES(kBvh, kLds) k_trac
                 pool_next = g; pool_base = g;
                 claim_end = (a.total_items - g < take) ? a.total_items : g + take;
                 // Generate the camera rays of the whole chunk now, all lanes busy, into this wave's staging
-                // rows in HBM; handing an item to a lane later is then eight loads.  (Generating on demand
+                // area in HBM; handing an item to a lane later is then three loads.  (Generating on demand
                 // ran this code on every trip of the main loop for the third of the lanes that had finished.)
                 uint32_t kept = 0;
                 // the list of the tile the current row belongs to: lane q holds candidate q (index and exact record), fetched when the tile changes
@@ -396,10 +396,12 @@ __global__ void __launch_bounds__(kTraceBlock) RT_TRACE_WAVES(kBvh, kLds) k_trac
                     const uint32_t slot = kept + __builtin_amdgcn_mbcnt_hi((uint32_t)(km >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)km, 0u));
                     kept += (uint32_t)__popcll(km);
                     if (keep) {
-                        staged[0 * kChunkItems + slot] = gr.o.x; staged[1 * kChunkItems + slot] = gr.o.y; staged[2 * kChunkItems + slot] = gr.o.z;
-                        staged[3 * kChunkItems + slot] = gr.d.x; staged[4 * kChunkItems + slot] = gr.d.y; staged[5 * kChunkItems + slot] = gr.d.z;
-                        staged[6 * kChunkItems + slot] = __uint_as_float(gp); staged[7 * kChunkItems + slot] = __uint_as_float(gs);
-                        staged[8 * kChunkItems + slot] = __uint_as_float(gstore); staged[9 * kChunkItems + slot] = __int_as_float(first);
+                        float* rec = staged + (size_t)slot * kStagedFloats;
+                        v4f ra, rb; v2f rc;
+                        ra.x = gr.o.x; ra.y = gr.o.y; ra.z = gr.o.z; ra.w = gr.d.x;
+                        rb.x = gr.d.y; rb.y = gr.d.z; rb.z = __uint_as_float(gp); rb.w = __uint_as_float(gs);
+                        rc.x = __uint_as_float(gstore); rc.y = __int_as_float(first);
+                        *reinterpret_cast<v4f*>(rec) = ra; *reinterpret_cast<v4f*>(rec + 4) = rb; *reinterpret_cast<v2f*>(rec + 8) = rc;
                     }
                 }
                 pool_end = g + kept;        // what is handed out is the staged rows, not the items
@@ -412,15 +414,13 @@ __global__ void __launch_bounds__(kTraceBlock) RT_TRACE_WAVES(kBvh, kLds) k_trac
             const uint32_t want = (uint32_t)__popcll(need);
             if (!active && rank < avail) {
                 const uint32_t slot = pool_next + rank - pool_base;
-                // device-scope loads: the staging rows are rewritten for every chunk, so a stale L1 line
-                // from the previous chunk must not be served
-                pix = __float_as_uint(staged_load(staged + 6 * kChunkItems + slot));
-                smp = __float_as_uint(staged_load(staged + 7 * kChunkItems + slot));
-                item = __float_as_uint(staged_load(staged + 8 * kChunkItems + slot));      // where the sample is stored
-                ray.o = mk(staged_load(staged + 0 * kChunkItems + slot), staged_load(staged + 1 * kChunkItems + slot), staged_load(staged + 2 * kChunkItems + slot));
-                ray.d = mk(staged_load(staged + 3 * kChunkItems + slot), staged_load(staged + 4 * kChunkItems + slot), staged_load(staged + 5 * kChunkItems + slot));
+                v4f ra, rb; v2f rc;
+                staged_read(staged + (size_t)slot * kStagedFloats, ra, rb, rc);
+                ray.o = mk(ra.x, ra.y, ra.z); ray.d = mk(ra.w, rb.x, rb.y);
+                pix = __float_as_uint(rb.z); smp = __float_as_uint(rb.w);
+                item = __float_as_uint(rc.x);               // where the sample is stored
                 // a staged second ray comes with the sphere its path left: the first entry of this lane's hit stack
-                const int first = __float_as_int(staged_load(staged + 9 * kChunkItems + slot));
+                const int first = __float_as_int(rc.y);
                 depth = 0;
                 if (first != kUnresolved) { stack[0] = (uint16_t)first; depth = 1; }
                 active = true;
@@ -598,7 +598,7 @@ int trace_prepare(rt_context* ctx, const RenderFrame& f, TracePlan* plan)
         (void)hipFree(ctx->d_stacks); ctx->d_stacks = nullptr; ctx->stacks_lanes = 0;
         (void)hipFree(ctx->d_staging); ctx->d_staging = nullptr;
         HIP_TRY(ctx, hipMalloc(&ctx->d_stacks, lanes * RT_MAX_DEPTH * sizeof(uint16_t)));
-        HIP_TRY(ctx, hipMalloc(&ctx->d_staging, (lanes / 64) * kStagingRows * kChunkItems * sizeof(float)));
+        HIP_TRY(ctx, hipMalloc(&ctx->d_staging, (lanes / 64) * kStagedFloats * kChunkItems * sizeof(float)));
         ctx->stacks_lanes = lanes;
     }
     const uint32_t n_tiles = (uint32_t)(f.Q / 64);
