@@ -30,33 +30,45 @@ __device__ __forceinline__ V3 unit(V3 a) { return a / length(a); }
 // ---------------------------------------------------------------------------- Philox4x32-10
 // Counter (pixel, sample, bounce, group), key = seed.  One call yields the four words of a group.
 struct U4 { uint32_t x, y, z, w; };
-__device__ __forceinline__ U4 philox4x32_10(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, uint32_t k0, uint32_t k1)
+// kWide: both halves of a product from one 64-bit multiply (v_mad_u64_u32) instead of a high and a low multiply -- half the
+// multiplier work, at the price of 64-bit register pairs; for code with registers to spare.
+template <bool kWide>
+__device__ __forceinline__ U4 philox4x32_10_t(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, uint32_t k0, uint32_t k1)
 {
 #pragma unroll
     for (int r = 0; r < 10; ++r) {
-        const uint32_t h0 = __umulhi(0xD2511F53u, c0), l0 = 0xD2511F53u * c0;
-        const uint32_t h1 = __umulhi(0xCD9E8D57u, c2), l1 = 0xCD9E8D57u * c2;
+        uint32_t h0, l0, h1, l1;
+        if (kWide) {
+            const unsigned long long p0 = (unsigned long long)0xD2511F53u * c0, p1 = (unsigned long long)0xCD9E8D57u * c2;
+            h0 = (uint32_t)(p0 >> 32); l0 = (uint32_t)p0; h1 = (uint32_t)(p1 >> 32); l1 = (uint32_t)p1;
+        } else {
+            h0 = __umulhi(0xD2511F53u, c0); l0 = 0xD2511F53u * c0;
+            h1 = __umulhi(0xCD9E8D57u, c2); l1 = 0xCD9E8D57u * c2;
+        }
         const uint32_t n0 = h1 ^ c1 ^ k0, n2 = h0 ^ c3 ^ k1;
         c0 = n0; c1 = l1; c2 = n2; c3 = l0;
         k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
     }
     U4 o; o.x = c0; o.y = c1; o.z = c2; o.w = c3; return o;
 }
+__device__ __forceinline__ U4 philox4x32_10(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, uint32_t k0, uint32_t k1) { return philox4x32_10_t<false>(c0, c1, c2, c3, k0, k1); }
 // 24-bit uniform in [0,1): exactly representable, equal to rand()/(RAND_MAX+1.0) for rand() = (w>>8)<<7.
 __device__ __forceinline__ float u01(uint32_t w) { return (float)(w >> 8) * (1.0f / 16777216.0f); }
 
 // Uniform providers.  f() is `static_cast<float>(rand()/(RAND_MAX+1.0))`, d() the double itself.
 // Keyed provider: draw d of the current slot is word d%4 of group d/4 (all four words of a Philox
 // block are consumed before the next block is computed).
-struct KeyedUniforms {
+template <bool kWide>
+struct KeyedUniformsT {
     uint32_t px, smp, bounce, k0, k1; U4 cur;
     __device__ __forceinline__ void slot(uint32_t p, uint32_t s, uint32_t b) { px = p; smp = s; bounce = b; }
     // Computes group 0 of the current slot (shared by whichever material consumes it).
-    __device__ __forceinline__ void prefetch() { cur = philox4x32_10(px, smp, bounce, 0u, k0, k1); }
+    __device__ __forceinline__ void prefetch() { cur = philox4x32_10_t<kWide>(px, smp, bounce, 0u, k0, k1); }
     // First draw of the slot (Dielectric::Scatter's only draw).
     __device__ __forceinline__ float f() { return u01(cur.x); }
     __device__ __forceinline__ double d() { return (double)f(); }
 };
+using KeyedUniforms = KeyedUniformsT<false>;
 // Replay provider for the unit-level entry points: recorded rand() integers.
 struct ReplayUniforms {
     const int32_t* draws; int pos;
@@ -116,16 +128,17 @@ __device__ __forceinline__ bool unit_ball_try(uint32_t wz, uint32_t wy, uint32_t
     p = 2.0f * mk(u01(wx), u01(wy), u01(wz)) - mk(1.0f, 1.0f, 1.0f);   // first draw is z: right-to-left argument order
     return !(sqlen(p) >= 1.0f);
 }
-__device__ __forceinline__ V3 random_in_unit_sphere(KeyedUniforms& u)
+template <bool kWide>
+__device__ __forceinline__ V3 random_in_unit_sphere(KeyedUniformsT<kWide>& u)
 {
     V3 p;
     U4 b0 = u.cur;
     for (uint32_t g = 0;; g += 3) {
-        if (g != 0) b0 = philox4x32_10(u.px, u.smp, u.bounce, g, u.k0, u.k1);
+        if (g != 0) b0 = philox4x32_10_t<kWide>(u.px, u.smp, u.bounce, g, u.k0, u.k1);
         if (unit_ball_try(b0.x, b0.y, b0.z, p)) break;
-        const U4 b1 = philox4x32_10(u.px, u.smp, u.bounce, g + 1u, u.k0, u.k1);
+        const U4 b1 = philox4x32_10_t<kWide>(u.px, u.smp, u.bounce, g + 1u, u.k0, u.k1);
         if (unit_ball_try(b0.w, b1.x, b1.y, p)) break;
-        const U4 b2 = philox4x32_10(u.px, u.smp, u.bounce, g + 2u, u.k0, u.k1);
+        const U4 b2 = philox4x32_10_t<kWide>(u.px, u.smp, u.bounce, g + 2u, u.k0, u.k1);
         if (unit_ball_try(b1.z, b1.w, b2.x, p)) break;
         if (unit_ball_try(b2.y, b2.z, b2.w, p)) break;
     }

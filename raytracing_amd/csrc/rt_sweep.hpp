@@ -28,9 +28,10 @@ __device__ __forceinline__ int owned_row_to_y2(int band_rows, int band_first, in
 
 // Camera ray of (pixel, sample): jitter from words 0,1 of group 0 (main.cpp:126-127), lens sample by
 // rejection from the words lens_words() names, then Camera::GetRay (camera.cpp:46-53).
+template <bool kWide = false>
 __device__ __forceinline__ RayD camera_ray(const CameraD& cam, uint32_t pix, uint32_t smp, int i, int j, float fnx, float fny, uint32_t k0, uint32_t k1)
 {
-    U4 blk = philox4x32_10(pix, smp, 0u, 0u, k0, k1);
+    U4 blk = philox4x32_10_t<kWide>(pix, smp, 0u, 0u, k0, k1);
     const float fu = (float)((double)i + (double)u01(blk.x)) / fnx;
     const float fv = (float)((double)j + (double)u01(blk.y)) / fny;
     float dx = 0.0f, dy = 0.0f;
@@ -42,7 +43,7 @@ __device__ __forceinline__ RayD camera_ray(const CameraD& cam, uint32_t pix, uin
             dx = 2.0f * a - 1.0f; dy = 2.0f * b - 1.0f;
             if (!((dx * dx) + (dy * dy) + 0.0f >= 1.0f)) break;
             ++t;
-            if (t & 1u) blk = philox4x32_10(pix, smp, 0u, (t + 1u) >> 1, k0, k1);
+            if (t & 1u) blk = philox4x32_10_t<kWide>(pix, smp, 0u, (t + 1u) >> 1, k0, k1);
         }
     }
     return get_ray(cam, fu, fv, dx, dy);
@@ -577,9 +578,9 @@ __device__ __forceinline__ void closest_hit_bvh(const RayD& ray, float tmin, con
 // path has ended (sample = its radiance); otherwise ray/depth are advanced and the hit index is pushed on
 // the lane's stack (element k at stack[k * sstride]).
 // kNoStack: for a camera ray (depth 0) whose caller records the hit index itself; nothing is pushed and there is nothing to replay.
-template <bool kLds, bool kNoStack = false>
+template <bool kLds, bool kNoStack = false, class Uniforms = KeyedUniforms>
 __device__ __forceinline__ bool shade_step(RayD& ray, int& depth, float closest, int hit, uint32_t pix, uint32_t smp, int max_depth,
-                                           KeyedUniforms& U, const float4* s_geom, const float4* s_mat, const Aux* s_aux,
+                                           Uniforms& U, const float4* s_geom, const float4* s_mat, const Aux* s_aux,
                                            const float4* g_geom, const float4* g_mat, const Aux* g_aux,
                                            uint16_t* stack, size_t sstride, V3& sample, SecTimer& T)
 {

@@ -245,6 +245,10 @@ __global__ void __launch_bounds__(256) k_tile_lists(const TileListArgs a)
 #endif
 #define RT_TRACE_WAVES(kBvh, kLds) __attribute__((amdgpu_waves_per_eu((kBvh) && (kLds) ? 4 : RT_WAVES, (kBvh) && (kLds) ? 4 : RT_WAVES)))
 #endif
+#ifndef RT_WIDE_PHILOX
+#define RT_WIDE_PHILOX 1
+#endif
+constexpr bool kWidePhilox = RT_WIDE_PHILOX != 0;     // the staging phase of k_trace has the registers for 64-bit products
 constexpr int kUnresolved = -2;             // staging row 9: the staged ray is the camera ray itself (no list for its tile), not the path's second ray
 template <bool kLds, bool kPlane, bool kBvh = false>
 __global__ void __launch_bounds__(kTraceBlock) RT_TRACE_WAVES(kBvh, kLds) k_trace(const TraceArgs a)
@@ -331,6 +335,7 @@ __global__ void __launch_bounds__(kTraceBlock) RT_TRACE_WAVES(kBvh, kLds) k_trac
                 // Generate the camera rays of the whole chunk now, all lanes busy, into this wave's staging
                 // area in HBM; handing an item to a lane later is then three loads.  (Generating on demand
                 // ran this code on every trip of the main loop for the third of the lanes that had finished.)
+                T.mark(0);
                 uint32_t kept = 0;
                 // the list of the tile the current row belongs to: lane q holds candidate q (index and exact record), fetched when the tile changes
                 uint32_t list_tile = 0xffffffffu, cnt = kNoTileList; int cand = 0; float4 crec = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
@@ -339,7 +344,7 @@ __global__ void __launch_bounds__(kTraceBlock) RT_TRACE_WAVES(kBvh, kLds) k_trac
                     uint32_t gp = 0xffffffffu, gs = 0u, gstore = 0u; int i = 0, j = 0;
                     RayD gr; gr.o = mk(0, 0, 0); gr.d = mk(0, 0, 0);
                     bool keep = decode_item(ig, it, gp, gs, i, j, gstore);         // padding pixels of edge tiles are dropped here
-                    if (keep) gr = camera_ray(a.cam, gp, gs, i, j, fnx, fny, a.k0, a.k1);
+                    if (keep) gr = camera_ray<kWidePhilox>(a.cam, gp, gs, i, j, fnx, fny, a.k0, a.k1);
                     // The first level of Color() for the camera ray, here, where the 64 lanes hold the rays of one tile: the closest
                     // hit over the tile's list (all lanes on the same few spheres, records as scalar loads, ascending sphere order
                     // with strict comparisons: HittableList::Hit's answer), then the shading step.  What is staged is the SECOND
@@ -382,7 +387,8 @@ __global__ void __launch_bounds__(kTraceBlock) RT_TRACE_WAVES(kBvh, kLds) k_trac
                             if (keep) {
                                 int d0 = 0; V3 sample;
                                 SecTimer untimed;            // (diagnostic build: the staging phase is timed as a whole)
-                                const bool done = shade_step<kLds, true>(gr, d0, pre_t, pre_k, gp, gs, a.max_depth, U, s_geom, s_mat, s_aux, a.geom, a.mat, a.aux, nullptr, 0, sample, untimed);
+                                KeyedUniformsT<kWidePhilox> UW; UW.k0 = a.k0; UW.k1 = a.k1;
+                                const bool done = shade_step<kLds, true>(gr, d0, pre_t, pre_k, gp, gs, a.max_depth, UW, s_geom, s_mat, s_aux, a.geom, a.mat, a.aux, nullptr, 0, sample, untimed);
                                 first = pre_k;
                                 if (done) {
                                     float* o = a.samples + (size_t)gstore * 3;
@@ -405,6 +411,7 @@ __global__ void __launch_bounds__(kTraceBlock) RT_TRACE_WAVES(kBvh, kLds) k_trac
                     }
                 }
                 pool_end = g + kept;        // what is handed out is the staged rows, not the items
+                T.mark(4);
                 // the rows are read back by other lanes of this wave: drain the stores first
                 __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
