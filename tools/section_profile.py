@@ -21,9 +21,9 @@ buf = (C.c_ulonglong * 8)()
 L.rt_debug_section_ticks(buf, 1)
 rgb, irgb, rays, ms = rt.render(rt.params(W, H, spp, seed=0))
 L.rt_debug_section_ticks(buf, 0)
-names = ["regenerate", "ray setup+filter", "exact pass A", "exact pass B", "sparse sweep", "hit record", "scatter", "sky+store"]
+names = ["hand-out", "ray setup+filter", "exact pass A", "exact pass B", "chunk staging (camera rays, first hit and shading) + sparse sweep", "hit record", "scatter", "sky+store"]
 order = [0, 1, 2, 3, 4, 5, 6, 7]
 tot = sum(buf[i] for i in order)
 print(f"{rays} rays, kernel {ms:.2f} ms (timers add overhead)")
 for i in order:
-    print(f"{names[i]:>14s} {100.0 * buf[i] / tot:5.1f} %")
+    print(f"{names[i]:>16s} {100.0 * buf[i] / tot:5.1f} %")
