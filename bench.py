@@ -144,6 +144,7 @@ def parse_args(argv):
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--workload", default="c3", choices=sorted(WORKLOADS))
     ap.add_argument("--spp", type=int, default=0, help="override samples per pixel")
+    ap.add_argument("--no-sweep-only", action="store_true", help="skip the extra renders with camera rays swept like every other ray (the sweep_only object of the line)")
     ap.add_argument("--band-rows", type=int, default=0, help="rows per band (0 = 8 on one GPU, 1 on several)")
     ap.add_argument("--seed", type=int, default=0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -422,7 +423,7 @@ def main(argv=None):
             line["config1"] = {"workload": f"c1: RTOW final random-spheres scene ({n_spheres} spheres), {width}x{height}, 10 spp, max depth 50",
                                "ms_per_step": wall1, "kernel_ms_mean": km, "kernel_ms_min": float(np.min(ms1)), "mrays_per_s": rays1 / (wall1 * 1e-3) / 1e6,
                                "roofline_frac": fr, "steps": 20}
-        if world == 1 and args.mode == "megakernel" and not os.environ.get("RT_AMD_PRIMARY"):
+        if world == 1 and args.mode == "megakernel" and not args.no_sweep_only and not os.environ.get("RT_AMD_PRIMARY"):
             # The same workload with camera rays swept over all spheres like every other ray (RT_AMD_PRIMARY=sweep is read when a
             # context is created): what the sweep alone delivers, outside the timed region above.
             os.environ["RT_AMD_PRIMARY"] = "sweep"
