@@ -649,7 +649,10 @@ int trace_batch(rt_context* ctx, const RenderFrame& f, const TracePlan& t, const
     a.bvh.nodes = ctx->d_bvh_nodes; a.bvh.leaf_index = ctx->d_bvh_leaf; a.bvh.big = ctx->d_bvh_big; a.bvh.n_big = ctx->bvh_n_big; a.bvh.geom = ctx->d_geom;
     // small jobs take smaller chunks so that every resident wave gets several (tail balance)
     const uint64_t resident_waves = (uint64_t)ctx->num_cu * t.blocks_per_cu * (kTraceBlock / 64);
-    uint64_t chunk = (uint64_t)a.total_items / (resident_waves * 16) / 64 * 64;
+#ifndef RT_CHUNK_DIV
+#define RT_CHUNK_DIV 16
+#endif
+    uint64_t chunk = (uint64_t)a.total_items / (resident_waves * RT_CHUNK_DIV) / 64 * 64;
     const uint64_t floor_items = (32768ull / (uint64_t)ctx->n_pad + 63) / 64 * 64;     // tiny scenes: keep per-chunk work above the hand-out overhead
     if (chunk < floor_items) chunk = floor_items;
     a.chunk_items = (int)(chunk < 64 ? 64 : (chunk > (uint64_t)kChunkItems ? (uint64_t)kChunkItems : chunk));
