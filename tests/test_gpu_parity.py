@@ -567,6 +567,78 @@ def test_camera_rays_through_tile_lists_equal_the_full_sweep(rt, monkeypatch):
     assert listed[11] < 0.8 and listed[12] == 0.0, shares
 
 
+def test_tile_lists_hold_every_sphere_an_extreme_ray_of_the_tile_hits(rt):
+    """The list of a tile against Sphere::Hit itself (sphere.cpp:15-52, restated here in numpy float32, which rounds every
+    operation like the reference's unfused code): rays at the corners of the tile's pixel rectangle (jitter 0 and 1 - 2^-24,
+    main.cpp:126-127) from points on the rim of the lens and its centre, produced by the library's Camera::GetRay
+    (rt_test_get_ray, camera.cpp:46-53), against every sphere.  Every sphere that reports a hit (discriminant > 0 and a root above
+    tmin) must be on the tile's list -- all of them, not only the closest one, which is what the image tests see."""
+    W, H = 200, 120
+    table = R.final_scene_table()
+    geom = np.asarray(table, dtype=np.float64)[:, 0:4].astype(np.float32)
+    top = np.float32(1.0) - np.float32(2.0 ** -24)
+    rim = []
+    for k in range(16):
+        a = 2.0 * np.pi * k / 16
+        dx, dy = np.float32(np.cos(a)), np.float32(np.sin(a))
+        while (dx * dx) + (dy * dy) + np.float32(0.0) >= np.float32(1.0):          # RandomUnitInDisk's acceptance test (camera.cpp:31-44)
+            dx, dy = dx * np.float32(0.9999999), dy * np.float32(0.9999999)
+        rim.append((dx, dy))
+    rim.append((np.float32(0.0), np.float32(0.0)))
+    rim = np.array(rim, dtype=np.float32)
+    for aperture, focus, tmin in ((0.1, 10.0, 0.001), (2.0, 6.0, 0.001), (0.6, 14.0, -50.0)):
+        ocam = O.make_camera((13.0, 2.0, 3.0), (0.0, 0.0, 0.0), (0.0, 1.0, 0.0), 20.0, np.float32(W) / np.float32(H), aperture, focus)
+        pod = R.CameraPod()
+        for dst, src in (("origin", "origin"), ("lower_left_corner", "llc"), ("horizontal", "horiz"), ("vertical", "vert"), ("u", "u"), ("v", "v"), ("w", "w")):
+            vec = getattr(ocam, src)
+            getattr(pod, dst)[:] = [vec.x, vec.y, vec.z]
+        pod.lens_radius = ocam.lens_radius
+        rt.upload_scene(table)
+        rt.set_camera(pod)
+        p = rt.params(W, H, 1, tmin=tmin)
+        counts, lists = rt.test_tile_lists(p)
+        tiles_x = (W + 7) // 8
+        assert (counts >= 0).mean() > 0.5, (aperture, (counts >= 0).mean())
+        # corner rays of every tile: (s, t) as the render loop forms them, times the lens points
+        ss, tt, dd, owner = [], [], [], []
+        for tile in range(len(counts)):
+            if counts[tile] < 0:
+                continue
+            ty, tx = divmod(tile, tiles_x)
+            i_lo, i_hi = tx * 8, min(tx * 8 + 7, W - 1)
+            y_lo, y_hi = ty * 8, min(ty * 8 + 7, H - 1)
+            for i, ui in ((i_lo, np.float32(0.0)), (i_hi, top)):
+                for y, uj in ((y_lo, top), (y_hi, np.float32(0.0))):
+                    j = H - 1 - y
+                    fu = np.float32(np.float64(i) + np.float64(ui)) / np.float32(W)
+                    fv = np.float32(np.float64(j) + np.float64(uj)) / np.float32(H)
+                    ss += [fu] * len(rim); tt += [fv] * len(rim); dd += list(rim); owner += [tile] * len(rim)
+        ro, rd = rt.test_get_ray(pod, np.array(ss, np.float32), np.array(tt, np.float32), np.array(dd, np.float32))
+        owner = np.array(owner)
+        on_list = np.zeros((len(counts), len(geom)), dtype=bool)
+        for tile in range(len(counts)):
+            on_list[tile, lists[tile, :max(counts[tile], 0)]] = True
+        f = np.float32
+        hits_seen = 0
+        for lo in range(0, len(owner), 4096):
+            o, d, own = ro[lo:lo + 4096, None, :], rd[lo:lo + 4096, None, :], owner[lo:lo + 4096]
+            oc = o - geom[None, :, 0:3]
+            dot = lambda a, b: (a[..., 0] * b[..., 0] + a[..., 1] * b[..., 1]) + a[..., 2] * b[..., 2]
+            a_ = dot(d, d); b_ = dot(oc, d); c_ = dot(oc, oc) - geom[None, :, 3] * geom[None, :, 3]
+            desc = b_ * b_ - a_ * c_
+            with np.errstate(invalid="ignore", divide="ignore"):
+                sq = np.sqrt(np.where(desc > 0, desc, f(0.0)))
+                hit = (desc > 0) & ((((-b_ - sq) / a_) > f(tmin)) | (((-b_ + sq) / a_) > f(tmin)))
+            assert desc.dtype == np.float32
+            missing = hit & ~on_list[own]
+            assert not missing.any(), (aperture, np.argwhere(missing)[:5], own[np.argwhere(missing)[:5, 0]])
+            hits_seen += int(hit.sum())
+        # the check has teeth: the rays do hit spheres (most of them the ground, many a small sphere too), and the lists are short
+        assert len(owner) == 68 * int((counts >= 0).sum()) and hits_seen > len(owner) // 2, (len(owner), hits_seen)
+        assert on_list.sum() < 0.05 * on_list.size
+        print(f"aperture {aperture}: {len(owner)} rays, {hits_seen} ray-sphere hits, all on the lists; mean list {on_list.sum() / max(1, (counts >= 0).sum()):.1f}")
+
+
 def test_tile_lists_of_the_final_scene_are_short(rt):
     """The benchmark's scene and camera (main.cpp:41-83, 111-116) at 1200x800: every tile has a list, and a list holds a few
     spheres of the 487 (2.1 on average, 11 at most when this was written)."""
