@@ -52,8 +52,8 @@ struct TraceArgs {
 // A persistent wave keeps all its lanes busy only while there are items left to hand out; once the counter
 // runs dry every wave drains the paths it still holds, and a wave with one 50-bounce path left costs as many
 // issue slots per bounce as a full one.  What is in flight at that moment is whatever was started LAST, so
-// tiles are worked on in order of how long their paths can get: tiles that show a metal or glass sphere
-// first, tiles that show only diffuse spheres next, tiles where every probe ray leaves the scene (one ray per
+// tiles are worked on in order of how long their paths can get: tiles that show a glass sphere first (a path can
+// bounce inside one up to the depth cap), then those that show a metal sphere, tiles that show only diffuse spheres next, tiles where every probe ray leaves the scene (one ray per
 // sample) last.  The order changes scheduling only: a sample's value and its slot in the sample buffer
 // depend on the image tile, not on when it is traced.
 struct TileArgs {
@@ -63,7 +63,7 @@ struct TileArgs {
 };
 
 // Eight probe rays per tile (corners and edge midpoints of the tile's pixel rectangle, through the lens
-// centre), one lane each; class = the largest over the probes of {0 miss, 1 lambertian, 2 metal/dielectric}.
+// centre), one lane each; class = the largest over the probes of {0 miss, 1 lambertian, 2 metal, 3 dielectric}.
 __global__ void __launch_bounds__(256) k_tile_class(const TileArgs a)
 {
     const uint32_t t = blockIdx.x * 256u + threadIdx.x;
@@ -96,44 +96,50 @@ __global__ void __launch_bounds__(256) k_tile_class(const TileArgs a)
                 if (temp < closest && temp > a.tmin) { closest = temp; hit = k; }
             }
         }
-        if (hit >= 0) cls = a.aux[hit].type == RT_LAMBERTIAN ? 1u : 2u;
+        if (hit >= 0) cls = a.aux[hit].type == RT_LAMBERTIAN ? 1u : a.aux[hit].type == RT_METAL ? 2u : 3u;
     }
     for (int off = 1; off < 8; off <<= 1) { const uint32_t o = (uint32_t)__shfl_xor((int)cls, off); cls = o > cls ? o : cls; }
     if (tile < a.tiles && sub == 0u) a.cls[tile] = cls;
 }
 
 // Stable counting sort of the tiles by class, highest class first (one block).
+constexpr int kTileClasses = 4;
 __global__ void __launch_bounds__(1024) k_tile_order(const TileArgs a)
 {
-    __shared__ uint32_t s_count[3];
-    __shared__ uint32_t s_wave[16][3];
-    __shared__ uint32_t s_run[3];
+    __shared__ uint32_t s_count[kTileClasses];
+    __shared__ uint32_t s_wave[16][kTileClasses];
+    __shared__ uint32_t s_run[kTileClasses];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    if (threadIdx.x < 3) s_count[threadIdx.x] = 0;
+    if (threadIdx.x < kTileClasses) s_count[threadIdx.x] = 0;
     __syncthreads();
-    uint32_t mine[3] = { 0, 0, 0 };
-    for (uint32_t i = threadIdx.x; i < a.tiles; i += 1024u) mine[a.cls[i]] += 1u;
-    for (int c = 0; c < 3; ++c) if (mine[c]) atomicAdd(&s_count[c], mine[c]);
+    uint32_t mine[kTileClasses] = {};
+    for (uint32_t i = threadIdx.x; i < a.tiles; i += 1024u) {
+        const uint32_t c = a.cls[i];
+#pragma unroll
+        for (int k = 0; k < kTileClasses; ++k) mine[k] += c == (uint32_t)k ? 1u : 0u;
+    }
+#pragma unroll
+    for (int c = 0; c < kTileClasses; ++c) if (mine[c]) atomicAdd(&s_count[c], mine[c]);
     __syncthreads();
-    if (threadIdx.x == 0) { s_run[2] = 0; s_run[1] = s_count[2]; s_run[0] = s_count[2] + s_count[1]; }
+    if (threadIdx.x == 0) { uint32_t run = 0; for (int c = kTileClasses - 1; c >= 0; --c) { s_run[c] = run; run += s_count[c]; } }
     __syncthreads();
     for (uint32_t base = 0; base < a.tiles; base += 1024u) {
         const uint32_t i = base + threadIdx.x;
-        const uint32_t c = i < a.tiles ? a.cls[i] : 3u;
+        const uint32_t c = i < a.tiles ? a.cls[i] : (uint32_t)kTileClasses;
         uint32_t rank = 0;
-        for (uint32_t k = 0; k < 3; ++k) {
+        for (uint32_t k = 0; k < (uint32_t)kTileClasses; ++k) {
             const unsigned long long m = __ballot(c == k);
             if (c == k) rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
             if (lane == 0) s_wave[wave][k] = (uint32_t)__popcll(m);
         }
         __syncthreads();
-        if (c < 3u) {
+        if (c < (uint32_t)kTileClasses) {
             uint32_t before = s_run[c];
             for (int w = 0; w < wave; ++w) before += s_wave[w][c];
             a.order[before + rank] = i;
         }
         __syncthreads();
-        if (threadIdx.x < 3) { uint32_t tot = 0; for (int w = 0; w < 16; ++w) tot += s_wave[w][threadIdx.x]; s_run[threadIdx.x] += tot; }
+        if (threadIdx.x < kTileClasses) { uint32_t tot = 0; for (int w = 0; w < 16; ++w) tot += s_wave[w][threadIdx.x]; s_run[threadIdx.x] += tot; }
         __syncthreads();
     }
 }
@@ -232,6 +238,23 @@ __global__ void __launch_bounds__(256) k_tile_lists(const TileListArgs a)
         count += (uint32_t)__popcll(m);
     }
     if (lane == 0) out[0] = count <= (uint32_t)(kTileListWords - 1) ? count : kNoTileList;
+}
+
+// Tile classes from the lists (see k_tile_class for what they are for): the list names every sphere a camera ray of the tile can
+// meet, so no glass sphere between the eight probe rays of k_tile_class is overlooked.  A tile without a list counts as glass.
+__global__ void __launch_bounds__(256) k_tile_class_from_lists(const uint32_t* lists, const Aux* aux, uint32_t tiles, uint32_t* cls)
+{
+    const uint32_t tile = blockIdx.x * 256u + threadIdx.x;
+    if (tile >= tiles) return;
+    const uint32_t* list = lists + (size_t)tile * kTileListWords;
+    const uint32_t count = list[0];
+    uint32_t c = count == kNoTileList ? 3u : 0u;
+    for (uint32_t q = 0; q < (count == kNoTileList ? 0u : count); ++q) {
+        const int type = aux[list[1 + q]].type;
+        const uint32_t k = type == RT_LAMBERTIAN ? 1u : type == RT_METAL ? 2u : 3u;
+        c = k > c ? k : c;
+    }
+    cls[tile] = c;
 }
 
 // Six waves per SIMD (three 512-thread blocks per CU) is what the LDS budget allows and what hides the latency of the exact
@@ -626,7 +649,8 @@ int trace_prepare(rt_context* ctx, const RenderFrame& f, TracePlan* plan)
     ta.ig.width = p->width; ta.ig.height = p->height; ta.ig.band_rows = p->band_rows; ta.ig.band_first = p->band_first; ta.ig.band_step = p->band_step;
     ta.ig.owned_rows = f.owned; ta.ig.tiles_x = f.tiles_x; ta.ig.Q = (uint32_t)f.Q; ta.ig.s_begin = 0; ta.ig.s_count = 1; ta.ig.tile_order = nullptr;
     ta.tiles = n_tiles; ta.cls = ctx->d_tile_cls; ta.order = ctx->d_tile_order;
-    hipLaunchKernelGGL(k_tile_class, dim3((n_tiles * 8u + 255u) / 256u), dim3(256), 0, st, ta);
+    if (ctx->primary_lists) hipLaunchKernelGGL(k_tile_class_from_lists, dim3((n_tiles + 255u) / 256u), dim3(256), 0, st, ctx->d_tile_lists, ctx->d_aux, n_tiles, ctx->d_tile_cls);
+    else hipLaunchKernelGGL(k_tile_class, dim3((n_tiles * 8u + 255u) / 256u), dim3(256), 0, st, ta);
     hipLaunchKernelGGL(k_tile_order, dim3(1), dim3(1024), 0, st, ta);
     HIP_TRY(ctx, hipGetLastError());
     ctx->tile_key = key; ctx->tile_key_valid = true;
