@@ -38,7 +38,7 @@ for case in range(cases):
     direction = rng.normal(size=3); direction /= np.linalg.norm(direction)
     look_at = rng.uniform(-0.3, 0.3, size=3) * spread
     vfov = float(np.clip(np.degrees(2 * np.arctan(1.5 * spread / max(dist, 1e-3))), 0.01, 120.0))
-    cam = R.Camera(look_at + direction * dist, look_at, (0.0, 1.0, 0.0), vfov, np.float32(W) / np.float32(H), float(rng.choice([0.0, 0.2])), max(dist, 0.1))
+    cam = R.Camera(look_at + direction * dist, look_at, (0.0, 1.0, 0.0), vfov, np.float32(W) / np.float32(H), float(rng.choice([0.0, 0.2, 0.2, 2.0]) * (spread if rng.random() < 0.3 else 1.0)), max(dist * float(rng.choice([1.0, 1.0, 0.3, 3.0])), 0.1))
     rt.upload_scene(table); rt.set_camera(cam)
     seed = 5000 + case
     lit = rt.render(rt.params(W, H, S, seed=seed, mode=R.MODE_PIXEL))
