@@ -223,7 +223,8 @@ int rt_test_helpers(rt_context *ctx, int n, const float *v, const float *normal,
  * are swept over all spheres), words 1.. = their indices in ascending order.  The first level of Color() (main.cpp:13-39) for a
  * camera ray searches only its tile's list, so every sphere HittableList::Hit (hittablelist.cpp:13-31) could report for a ray of the
  * tile (Camera::GetRay, camera.cpp:46-53, over the tile's pixels, all jitters and the whole lens) has to be on it.  *tiles receives
- * the number of tiles; RT_ERR_TOO_LARGE when capacity_words < 64 * *tiles. */
+ * the number of tiles; RT_ERR_TOO_LARGE when capacity_words < 64 * *tiles.  The lists live in the context and are rebuilt by every
+ * render call: like every call on a context, not to be made while another call on the same context is in flight. */
 int rt_test_tile_lists(rt_context *ctx, const rt_params *p, uint32_t *lists, int64_t capacity_words, int64_t *tiles);
 /* Philox4x32-10 blocks: ctr[4n], key[2] -> out[4n]. */
 int rt_test_philox(rt_context *ctx, int n, const uint32_t *ctr, const uint32_t *key, uint32_t *out);
