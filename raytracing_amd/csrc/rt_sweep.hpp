@@ -63,12 +63,13 @@ struct BvhScene {
 static __device__ unsigned long long g_wave_times[8][8192];      // rows 4, 5: trips made with the sparse sweep, ticks spent in those trips (whole trip); 6: first sweep starts; 7: first trip ends
 #endif
 #ifdef RT_SECTION_TIMERS
-static __device__ unsigned long long g_section_ticks[8];
+static constexpr int kSections = 12;
+static __device__ unsigned long long g_section_ticks[kSections];
 struct SecTimer {
-    unsigned long long acc[8]; unsigned long long last;
-    __device__ __forceinline__ void start() { for (int k = 0; k < 8; ++k) acc[k] = 0; last = __builtin_amdgcn_s_memtime(); }
+    unsigned long long acc[kSections]; unsigned long long last;
+    __device__ __forceinline__ void start() { for (int k = 0; k < kSections; ++k) acc[k] = 0; last = __builtin_amdgcn_s_memtime(); }
     __device__ __forceinline__ void mark(int idx) { const unsigned long long t = __builtin_amdgcn_s_memtime(); acc[idx] += t - last; last = t; }
-    __device__ __forceinline__ void flush(int lane) { if (lane == 0) for (int k = 0; k < 8; ++k) atomicAdd(&g_section_ticks[k], acc[k]); }
+    __device__ __forceinline__ void flush(int lane) { if (lane == 0) for (int k = 0; k < kSections; ++k) atomicAdd(&g_section_ticks[k], acc[k]); }
 };
 #else
 struct SecTimer {

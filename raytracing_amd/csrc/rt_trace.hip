@@ -368,6 +368,7 @@ __global__ void __launch_bounds__(kTraceBlock) RT_TRACE_WAVES(kBvh, kLds) k_trac
                     RayD gr; gr.o = mk(0, 0, 0); gr.d = mk(0, 0, 0);
                     bool keep = decode_item(ig, it, gp, gs, i, j, gstore);         // padding pixels of edge tiles are dropped here
                     if (keep) gr = camera_ray<kWidePhilox>(a.cam, gp, gs, i, j, fnx, fny, a.k0, a.k1);
+                    T.mark(8);
                     // The first level of Color() for the camera ray, here, where the 64 lanes hold the rays of one tile: the closest
                     // hit over the tile's list (all lanes on the same few spheres, records as scalar loads, ascending sphere order
                     // with strict comparisons: HittableList::Hit's answer), then the shading step.  What is staged is the SECOND
@@ -406,6 +407,7 @@ __global__ void __launch_bounds__(kTraceBlock) RT_TRACE_WAVES(kBvh, kLds) k_trac
                                     if (temp < pre_t && temp > a.tmin) { pre_t = temp; pre_k = k; }
                                 }
                             }
+                            T.mark(9);
                             rays += (uint32_t)__popcll(__ballot(keep)); misses += (uint32_t)__popcll(__ballot(keep && pre_k < 0));
                             if (keep) {
                                 int d0 = 0; V3 sample;
@@ -421,6 +423,7 @@ __global__ void __launch_bounds__(kTraceBlock) RT_TRACE_WAVES(kBvh, kLds) k_trac
                             }
                         }
                     }
+                    T.mark(10);
                     const unsigned long long km = __ballot(keep);
                     const uint32_t slot = kept + __builtin_amdgcn_mbcnt_hi((uint32_t)(km >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)km, 0u));
                     kept += (uint32_t)__popcll(km);
@@ -434,7 +437,7 @@ __global__ void __launch_bounds__(kTraceBlock) RT_TRACE_WAVES(kBvh, kLds) k_trac
                     }
                 }
                 pool_end = g + kept;        // what is handed out is the staged rows, not the items
-                T.mark(4);
+                T.mark(11);
                 // the rows are read back by other lanes of this wave: drain the stores first
                 __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -538,10 +541,10 @@ __global__ void __launch_bounds__(256) k_resolve(const ResolveArgs a)
     if (a.irgb) { a.irgb[o] = quantise(mr); a.irgb[o + 1] = quantise(mg); a.irgb[o + 2] = quantise(mb); }
 }
 #ifdef RT_SECTION_TIMERS
-extern "C" int rt_debug_section_ticks(unsigned long long* out8, int reset)
+extern "C" int rt_debug_section_ticks(unsigned long long* out8, int reset)   /* kSections (12) values */
 {
-    if (out8 && hipMemcpyFromSymbol(out8, HIP_SYMBOL(g_section_ticks), 8 * sizeof(unsigned long long)) != hipSuccess) return -3;
-    if (reset) { unsigned long long z[8] = { 0 }; if (hipMemcpyToSymbol(HIP_SYMBOL(g_section_ticks), z, sizeof z) != hipSuccess) return -3; }
+    if (out8 && hipMemcpyFromSymbol(out8, HIP_SYMBOL(g_section_ticks), kSections * sizeof(unsigned long long)) != hipSuccess) return -3;
+    if (reset) { unsigned long long z[kSections] = { 0 }; if (hipMemcpyToSymbol(HIP_SYMBOL(g_section_ticks), z, sizeof z) != hipSuccess) return -3; }
     return 0;
 }
 #endif

@@ -14,7 +14,7 @@ table = np.vstack([R.final_scene_table(), [[100.0, 50.0, 100.0, -1.0, R.METAL, 0
 rt.upload_scene(table)
 rt.set_camera(R.Camera((100.0, 50.0, 100.0), (101.0, 50.2, 100.3), (0.0, 1.0, 0.0), 40.0, 1.0, 0.0, 1.0))
 L = R.load_library()
-buf = (C.c_ulonglong * 8)()
+buf = (C.c_ulonglong * 12)()
 names = ["hand-out", "ray setup+filter", "exact pass A", "exact pass B", "sparse sweep (incl. loop top)", "hit record", "scatter", "sky+store"]
 for w in (1, 4):
     rt.render(rt.params(w, 1, 1, seed=0, max_depth=64))

@@ -17,13 +17,14 @@ rt = R.Renderer(0)
 rt.upload_scene(R.scene_grid(42, 75, 19996) if big else R.final_scene_table())
 rt.set_camera(R.final_camera(W, H))
 L = R.load_library()
-buf = (C.c_ulonglong * 8)()
+buf = (C.c_ulonglong * 12)()
 L.rt_debug_section_ticks(buf, 1)
 rgb, irgb, rays, ms = rt.render(rt.params(W, H, spp, seed=0))
 L.rt_debug_section_ticks(buf, 0)
-names = ["hand-out", "ray setup+filter", "exact pass A", "exact pass B", "chunk staging (camera rays, first hit and shading) + sparse sweep", "hit record", "scatter", "sky+store"]
-order = [0, 1, 2, 3, 4, 5, 6, 7]
+names = ["hand-out", "ray setup+filter", "exact pass A", "exact pass B", "sparse sweep", "hit record", "scatter", "sky+store",
+         "staging: camera rays", "staging: first hit over the tile list", "staging: first shading step", "staging: compaction, stores, wait"]
+order = [0, 8, 9, 10, 11, 1, 2, 3, 4, 5, 6, 7]
 tot = sum(buf[i] for i in order)
 print(f"{rays} rays, kernel {ms:.2f} ms (timers add overhead)")
 for i in order:
-    print(f"{names[i]:>16s} {100.0 * buf[i] / tot:5.1f} %")
+    print(f"{names[i]:>40s} {100.0 * buf[i] / tot:5.1f} %")
