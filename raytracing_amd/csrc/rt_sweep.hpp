@@ -339,8 +339,10 @@ __device__ __forceinline__ void closest_hit(const RayD& ray, float tmin, const S
                 const uint32_t bit = 0x80000000u >> jj;
                 cand ^= bit;                   // the bit is set: a two-cycle xor instead of a four-cycle and-not
                 const int k = cbase + jj;
-                const float4 g = kLds ? lds.geom[k] : sw.geom[k];
-                const float dk = !kLds ? sw.frec[k].w : kPacked ? g.w : lds.disck[k];
+                // without the LDS mirror the discriminant-filter record itself is gathered: it holds the same centre as the exact
+                // record and the constant beside it (one 16-byte load per survivor instead of two)
+                const float4 g = kLds ? lds.geom[k] : sw.frec[k];
+                const float dk = !kLds ? g.w : kPacked ? g.w : lds.disck[k];
                 const float b = fmaf(g.x, hx, fmaf(g.y, hy, fmaf(g.z, hz, nod)));
                 const float ew = fmaf(g.x, p2x, fmaf(g.y, p2y, fmaf(g.z, p2z, noo)));
                 const float e = fmaf(b, b, ew);
