@@ -1,7 +1,9 @@
 """Kernel time of every rank's share of config 3 when the image is split over G GPUs in interleaved bands of `band` rows,
 against 1/G of the single-GPU time: what the multi-GPU bench can reach at best (the slowest rank sets the step time)."""
+import os
 import sys
 import torch
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import raytracing_amd as R
 
 rt = R.Renderer(0)
