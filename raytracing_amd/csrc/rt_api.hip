@@ -47,7 +47,8 @@ int rt_create(int device_ordinal, rt_context** out)
     if (!ctx) return fail(nullptr, RT_ERR_HIP, "rt_create: out of host memory");
     ctx->device = device_ordinal;
     // RT_AMD_FILTER=disc selects the full-discriminant filter instead of the plane filter (A/B runs).
-    { const char* f = getenv("RT_AMD_FILTER"); ctx->plane_filter = !(f && strcmp(f, "disc") == 0); }
+    // RT_AMD_FILTER=plane keeps the plane filter on the vector ALU (records as scalar operands) instead of the matrix pipe.
+    { const char* f = getenv("RT_AMD_FILTER"); ctx->plane_filter = !(f && strcmp(f, "disc") == 0); ctx->mfma_filter = !(f && (strcmp(f, "disc") == 0 || strcmp(f, "plane") == 0)); }
     // RT_AMD_TILE_ORDER=image works through the tiles in image order instead of longest-paths-first (A/B runs).
     // RT_AMD_SAMPLE_BUFFER_KB caps the sample buffer (tests use it to run the multi-batch path on small images).
     { const char* f = getenv("RT_AMD_SAMPLE_BUFFER_KB"); const long long kb = f ? atoll(f) : 0; if (kb > 0) ctx->sample_buffer_cap = (uint64_t)kb << 10; }
@@ -72,7 +73,7 @@ void rt_destroy(rt_context* ctx)
     if (ctx->pending) (void)hipStreamSynchronize(ctx->last_stream);
     (void)hipFree(ctx->d_geom); (void)hipFree(ctx->d_mat); (void)hipFree(ctx->d_aux); (void)hipFree(ctx->d_rays); (void)hipFree(ctx->d_ppm_scratch); (void)hipFree(ctx->d_out_rgb); (void)hipFree(ctx->d_out_irgb);
     (void)hipFree(ctx->d_bvh_nodes); (void)hipFree(ctx->d_bvh_leaf); (void)hipFree(ctx->d_bvh_big);
-    (void)hipFree(ctx->d_frec); (void)hipFree(ctx->d_prec); (void)hipFree(ctx->d_force); (void)hipFree(ctx->d_samples); (void)hipFree(ctx->d_accum); (void)hipFree(ctx->d_work); (void)hipFree(ctx->d_stacks); (void)hipFree(ctx->d_staging); (void)hipFree(ctx->d_tile_cls); (void)hipFree(ctx->d_tile_order); (void)hipFree(ctx->d_tile_lists);
+    (void)hipFree(ctx->d_frec); (void)hipFree(ctx->d_prec); (void)hipFree(ctx->d_arec); (void)hipFree(ctx->d_force); (void)hipFree(ctx->d_samples); (void)hipFree(ctx->d_accum); (void)hipFree(ctx->d_work); (void)hipFree(ctx->d_stacks); (void)hipFree(ctx->d_staging); (void)hipFree(ctx->d_tile_cls); (void)hipFree(ctx->d_tile_order); (void)hipFree(ctx->d_tile_lists);
     (void)hipFree(ctx->wf_ray); (void)hipFree(ctx->wf_pixsmp); (void)hipFree(ctx->wf_depth); (void)hipFree(ctx->wf_hit_t); (void)hipFree(ctx->wf_hit_idx);
     (void)hipFree(ctx->wf_stacks); (void)hipFree(ctx->wf_q[0]); (void)hipFree(ctx->wf_q[1]); (void)hipFree(ctx->wf_n);
     if (ctx->ev0) (void)hipEventDestroy(ctx->ev0);
@@ -145,8 +146,45 @@ int rt_upload_scene(rt_context* ctx, int n, const float* cx, const float* cy, co
         slot[64] = (float)(1.0 / rho);
         force[n_words + (base >> 9)] |= 0x8000u >> ((base >> 5) & 15);
     }
+    // The same filter for the matrix pipe (filter_mfma in rt_sweep.hpp): every judged sphere normalised by its own rho, as bf16
+    // heads and tails.  q is formed from bf16 pieces whose omitted cross terms and tails are < 2^-14 of the three products'
+    // magnitudes (2^-13 is allowed for, which also covers the accumulator's roundings and those of the kernel's float normal):
+    //   rho >= sqrt(R) + 2^-13 (|cx| + |cz|), and 1 / rho rounded DOWN to a bf16 number (rho grows by < 2^-7 of itself);
+    //   the ray's share, 2^-13 |o.u| <= 2^-13 (|o.x| + |o.z|), shrinks the ray's normal by the factor 1 - (|o.x| + |o.z|) g with
+    //   g = 2^-13 / sqrt(min R) (mfma_g), which brings kappa |pu| + 2^-13 |o.u| under sqrt(R) for every judged sphere.
+    // Row order inside a chunk: the instruction returns rows 8 (v / 4) + 4 h + v % 4 to lane half h, register v, and the
+    // kernel wants those to be spheres 16 h + v.  Spheres that are not judged, and padding, get NaN records: no ray passes.
+    const int n_chunks = (n + 31) / 32;
+    std::vector<uint16_t> arec((size_t)n_chunks * 64 * 4, (uint16_t)0x7fc0);
+    auto bf16_rn = [](double x) -> uint16_t {           // nearest bf16, ties to even; x finite
+        const float f = (float)x; uint32_t b; memcpy(&b, &f, 4);
+        // a double rounded to float first can round twice; the one extra half-ulp of the float (2^-25 relative) is nothing here
+        b += 0x7fffu + ((b >> 16) & 1u);
+        return (uint16_t)(b >> 16);
+    };
+    auto bf16_val = [](uint16_t h) -> double { const uint32_t b = (uint32_t)h << 16; float f; memcpy(&f, &b, 4); return (double)f; };
+    for (int i = 0; i < n; ++i) {
+        if (!judged_flag[i]) continue;
+        const double rho = (std::sqrt((double)Rof[i]) + 0x1p-13 * (std::fabs((double)cx[i]) + std::fabs((double)cz[i]))) * (1.0 + 1e-6);
+        const float irf = (float)(1.0 / rho); uint32_t ib; memcpy(&ib, &irf, 4);
+        if ((double)irf > 1.0 / rho) --ib;
+        const uint16_t ir = (uint16_t)(ib >> 16);                   // truncation of a positive float: rounded down
+        const double irv = bf16_val(ir);
+        const double ax = (double)cx[i] * irv, az = (double)cz[i] * irv;
+        const bool fits = irv >= 0x1p-60 && irv <= 0x1p60 && std::fabs(ax) <= 0x1p60 && std::fabs(az) <= 0x1p60;
+        if (!fits) { force[i >> 5] |= 0x80000000u >> (i & 31); ++n_forced; continue; }     // (forced for every filter form: always a candidate)
+        const uint16_t axh = bf16_rn(ax), azh = bf16_rn(az);
+        const uint16_t axl = bf16_rn(ax - bf16_val(axh)), azl = bf16_rn(az - bf16_val(azh));
+        const int c = i >> 5, j = i & 31, h = j >> 4, v = j & 15;
+        const int row = 8 * (v >> 2) + 4 * h + (v & 3);
+        uint16_t* lo = &arec[((size_t)c * 64 + row) * 4];            // lane `row`: k 0..3
+        uint16_t* hi = &arec[((size_t)c * 64 + 32 + row) * 4];       // lane 32 + `row`: k 4..7
+        lo[0] = axh; lo[1] = axl; lo[2] = axh; lo[3] = azh;
+        hi[0] = azl; hi[1] = azh; hi[2] = ir; hi[3] = ir;
+    }
     const float plane_s0 = 1e-30f;
     if (rmin_R > 1e29) rmin_R = 1.0;
+    float mfma_g = (float)(0x1p-13 / std::sqrt(rmin_R) * (1.0 + 1e-6)); mfma_g = nextafterf(mfma_g, INFINITY);
     const float plane_rmin = nextafterf((float)rmin_R, 0.0f);
     for (int i = 0; i < n; ++i) {
         if (material[i] < RT_LAMBERTIAN || material[i] > RT_DIELECTRIC) return fail(ctx, RT_ERR_INVALID, "rt_upload_scene: sphere %d has unknown material %d", i, material[i]);
@@ -157,8 +195,11 @@ int rt_upload_scene(rt_context* ctx, int n, const float* cx, const float* cy, co
     }
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     if (ctx->pending) { HIP_TRY(ctx, hipStreamSynchronize(ctx->last_stream)); ctx->pending = false; }
-    (void)hipFree(ctx->d_geom); (void)hipFree(ctx->d_mat); (void)hipFree(ctx->d_aux); (void)hipFree(ctx->d_frec); (void)hipFree(ctx->d_prec); (void)hipFree(ctx->d_force);
-    ctx->d_geom = nullptr; ctx->d_mat = nullptr; ctx->d_aux = nullptr; ctx->d_frec = nullptr; ctx->d_prec = nullptr; ctx->d_force = nullptr; ctx->n = 0;
+    (void)hipFree(ctx->d_geom); (void)hipFree(ctx->d_mat); (void)hipFree(ctx->d_aux); (void)hipFree(ctx->d_frec); (void)hipFree(ctx->d_prec); (void)hipFree(ctx->d_arec); (void)hipFree(ctx->d_force);
+    ctx->d_geom = nullptr; ctx->d_mat = nullptr; ctx->d_aux = nullptr; ctx->d_frec = nullptr; ctx->d_prec = nullptr; ctx->d_arec = nullptr; ctx->d_force = nullptr; ctx->n = 0;
+    HIP_TRY(ctx, hipMalloc(&ctx->d_arec, arec.size() * sizeof(uint16_t)));
+    HIP_TRY(ctx, hipMemcpy(ctx->d_arec, arec.data(), arec.size() * sizeof(uint16_t), hipMemcpyHostToDevice));
+    ctx->mfma_g = mfma_g;
     HIP_TRY(ctx, hipMalloc(&ctx->d_prec, sizeof(float4) * n_pad));
     HIP_TRY(ctx, hipMemcpy(ctx->d_prec, prec.data(), sizeof(float4) * n_pad, hipMemcpyHostToDevice));
     HIP_TRY(ctx, hipMalloc(&ctx->d_force, sizeof(uint32_t) * force.size()));

@@ -22,6 +22,7 @@ struct rt_context {
     float4* d_geom = nullptr; float4* d_mat = nullptr; Aux* d_aux = nullptr; int n = 0;
     float4* d_frec = nullptr; float4* d_prec = nullptr; uint32_t* d_force = nullptr; int n_forced = 0; float plane_s0 = 0.0f; float plane_rmin = 1.0f; int n_pad = 0;
     bool plane_filter = true;
+    uint2* d_arec = nullptr; float mfma_g = 0.0f; bool mfma_filter = true;     // matrix-pipe form of the plane filter (closest_hit in rt_sweep.hpp)
     float* d_samples = nullptr; size_t samples_bytes = 0;      // sample buffer of the persistent megakernel
     uint64_t sample_buffer_cap = 16ull << 30;                  // largest sample buffer per batch (bytes)
     float* d_accum = nullptr; size_t accum_bytes = 0;          // running per-pixel sums across sample batches
@@ -39,7 +40,7 @@ struct rt_context {
     uint32_t wf_P = 0; float* wf_ray = nullptr; uint32_t* wf_pixsmp = nullptr; int* wf_depth = nullptr; float* wf_hit_t = nullptr; int* wf_hit_idx = nullptr;
     uint16_t* wf_stacks = nullptr; uint32_t* wf_q[2] = { nullptr, nullptr }; uint32_t* wf_n = nullptr;
     int wf_blocks_per_cu[4] = { 0, 0, 0, 0 };
-    int num_cu = 0; int trace_blocks_per_cu[6] = { 0, 0, 0, 0, 0, 0 };
+    int num_cu = 0; int trace_blocks_per_cu[8] = { 0, 0, 0, 0, 0, 0, 0, 0 };
     // sphere hierarchy of RT_MODE_BVH (rt_bvh.hpp), rebuilt with every scene upload
     float4* d_bvh_nodes = nullptr; uint32_t* d_bvh_leaf = nullptr; uint32_t* d_bvh_big = nullptr; int bvh_n_big = 0, bvh_depth = 0, bvh_nodes = 0;
     bool have_camera = false; CameraD cam{};
@@ -65,7 +66,7 @@ struct RenderFrame {
 };
 struct SampleBatch { int index, s0, sc; };
 // What trace_prepare settles once per call for the batches of k_trace.
-struct TracePlan { bool lds, plane, bvh, ordered; size_t shmem; int blocks_per_cu; };
+struct TracePlan { bool lds, plane, bvh, mfma, ordered; size_t shmem; int blocks_per_cu, block; };
 
 #define RT_HIDDEN __attribute__((visibility("hidden")))
 int pixel_render(rt_context* ctx, const RenderFrame& f) RT_HIDDEN;                                              // rt_pixel.hip

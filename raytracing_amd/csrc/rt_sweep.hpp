@@ -84,6 +84,9 @@ struct SecTimer {
 static constexpr int kChunkItems = RT_CHUNK_ITEMS;
 static constexpr int kStagedFloats = 16;       // one staged ray: 64 bytes (origin, direction, pixel key, sample, sample-buffer slot, first sphere, padding)
 static constexpr int kTraceBlock = 512;         // 8 waves share one LDS copy of the scene records
+// k_trace with the matrix-pipe filter keeps that filter's A operands in LDS too (8 KB more at 487 spheres): 12 waves share one copy,
+// two such blocks per CU are the same six waves per SIMD
+__host__ __device__ constexpr int trace_block(bool mfma) { return mfma ? 768 : kTraceBlock; }
 // A staged ray is read back by another lane of the wave that wrote it, and its slot is rewritten for every chunk: the loads are
 // device-scope ones (sc1), so that a line of the previous chunk still in this CU's L1 is not served.  Three loads off one address
 // and one wait for the lot.
@@ -115,13 +118,15 @@ struct SweepScene {
     int n_forced;            // how many bits are set in `force`
     const float4* geom;      // exact records in HBM (used when they are not mirrored in LDS)
     int n, n_pad;
+    const uint2* arec;       // matrix-pipe form of the plane filter: per chunk of 32 spheres, 64 x 8 bytes (one MFMA A operand, see filter_mfma)
+    float mfma_g;            // per-ray allowance of that form: kappa is scaled by 1 - (|o.x| + |o.z|) mfma_g
 };
 
 // LDS mirror of the records the exact passes read.  Packed form (k_trace): geom[k] = (centre, constant of the discriminant
 // filter) and r*r is formed from aux[k].radius -- the same single float product the host stores in the HBM record -- so a sphere
 // costs no more LDS than before the filter constant moved in.  Plain form (wavefront intersect): geom[k] = (centre, r*r) as in
 // HBM and the constants in an array of their own.
-struct ExactLds { const float4* geom; const Aux* aux; const float* disck; };
+struct ExactLds { const float4* geom; const Aux* aux; const float* disck; const uint2* arec = nullptr; /* LDS copy of SweepScene::arec (k_trace, matrix-pipe filter) */ };
 template <bool kFromRadius>
 __device__ __forceinline__ float exact_r2(const float4& g, const ExactLds& lds, int k)
 {
@@ -129,10 +134,29 @@ __device__ __forceinline__ float exact_r2(const float4& g, const ExactLds& lds, 
     return g.w;
 }
 
-template <bool kLds, bool kPlane, bool kPacked>
-__device__ __forceinline__ void closest_hit(const RayD& ray, float tmin, const SweepScene& sw, const ExactLds& lds,
-                                            uint32_t* mask_words, float& closest, int& hit, SecTimer& T)
+typedef float f16acc __attribute__((ext_vector_type(16)));
+typedef short bf16x4 __attribute__((ext_vector_type(4)));
+// a's lanes 32-63 <-> b's lanes 0-31
+__device__ __forceinline__ void swap_halves(uint32_t& a, uint32_t& b)
 {
+    const auto r = __builtin_amdgcn_permlane32_swap(a, b, false, false);
+    a = r[0]; b = r[1];
+}
+// x rounded to the nearest bf16 (ties to even), as the bits of a float (low half zero).  Not for NaN.
+__device__ __forceinline__ uint32_t bf16_bits(float x)
+{
+    const uint32_t b = __float_as_uint(x);
+    return (b + 0x7fffu + ((b >> 16) & 1u)) & 0xffff0000u;
+}
+
+template <bool kLds, bool kPlane, bool kPacked, bool kMfma = false>
+__device__ __forceinline__ void closest_hit(const RayD& ray, float tmin, const SweepScene& sw, const ExactLds& lds,
+                                            uint32_t* mask_words, float& closest, int& hit, SecTimer& T, bool active = true)
+{
+    // kMfma: the plane filter's dot product runs on the matrix pipe (filter_mfma below).  The matrix instruction and the
+    // half-wave swaps around it work on the whole wave, so in this form the function is entered by ALL 64 lanes of the wave;
+    // a lane without a ray (active == false) is given a NaN normal, which fails every test, and leaves with hit = -1.
+    static_assert(!kMfma || kPlane, "the matrix-pipe filter is a form of the plane filter");
     // Per ray: unit direction (approximate is enough for a conservative test), -(o.d^), 2o,
     // -|o|^2 (1 - slack).  Per sphere record (cx, cy, cz, k), k = |c|^2 - r^2 - slack_i:
     //   b = c.d^ - o.d^            3 FMA      w = 2 o.c - |o|^2'        3 FMA
@@ -160,7 +184,10 @@ __device__ __forceinline__ void closest_hit(const RayD& ray, float tmin, const S
         // R_i >= Rmin, so the per-pair test is the sign of R_i - pu'^2 alone (3 FMA per pair).
         s_ray = fmaf(kPlaneRaySlack, oo, sw.plane_s0);
         const float k2 = sw.plane_rmin / (sw.plane_rmin + s_ray);
-        const float kappa = sqrtf(k2) * (1.0f - 4.0f * 5.9604645e-08f);
+        float kappa = sqrtf(k2) * (1.0f - 4.0f * 5.9604645e-08f);
+        // The bf16 pieces the matrix pipe multiplies leave pu off by up to 2^-13 (|cx| + |cz| + |o.u|): the sphere's part is in its
+        // record (host), the ray's part shrinks the normal once more (|o.u| <= |o.x| + |o.z|; kappa = 0 passes every sphere)
+        if (kMfma) kappa *= fmaxf(0.0f, 1.0f - (fabsf(ray.o.x) + fabsf(ray.o.z)) * sw.mfma_g);
         ux *= kappa; uz *= kappa;
         nou = -fmaf(ray.o.x, ux, ray.o.z * uz);
         // The verdict of a pair is wanted as the number 0.0 or 1.0 (see filter_bits): everything is scaled by 2^44 (exact),
@@ -265,7 +292,47 @@ __device__ __forceinline__ void closest_hit(const RayD& ray, float tmin, const S
         }
         return ((uint32_t)acc0 << 16) | (uint32_t)acc1;
     };
-    const float threshold88 = 0x1p88f;       // handed to the FMA as a vector-register operand
+    float threshold88 = 0x1p88f;       // handed to the FMA as a vector-register operand
+    // Matrix-pipe form.  q = (cx ux + cz uz - o.u) / rho of 32 spheres x 32 rays per v_mfma_f32_32x32x8_bf16_1k: every factor
+    // is split into a bf16 head and tail (x = xh + xl up to 2^-16 |x|) and the eight products kept are
+    //   axh uxh + axl uxh + axh uxl  +  azh uzh + azl uzh + azh uzl  +  ir nh + ir nl        (a = c / rho, ir = 1 / rho a bf16 number),
+    // exact in the f32 accumulator, so q is off by < 2^-14 (|ax ux| + |az uz| + |ir o.u|) + the accumulator's roundings; the host
+    // widens rho and mfma_g shrinks the normal for 2^-13 of those magnitudes.  Operand layout: lane l supplies row / column l % 32
+    // and k = 4 (l / 32) .. + 3.  A comes ready-made from the host (SweepScene::arec); B is built here from the lane's own ray
+    // -- k 0-3 in L, k 4-7 in H -- and two half-wave swaps turn (L, H) into the operands for rays 0-31 and for rays 32-63.
+    // Result layout: lane l holds column l % 32 and rows 8 (v / 4) + 4 (l / 32) + v % 4, v = 0..15; the host orders a chunk's rows so
+    // that these are spheres 16 (l / 32) + v.  Verdict and accumulate are the two all-VGPR FMAs of filter_norm; the chain starts at
+    // 128, so that it ends as 2^23 + the sixteen verdict bits, i.e. with those bits in the low half of the float's pattern and no
+    // conversion; one more swap hands every lane the two halves of ITS ray's word.
+    bf16x4 mb1 = { 0, 0, 0, 0 }, mb2 = { 0, 0, 0, 0 };
+    if constexpr (kMfma) {
+        if (!active) ux = __builtin_nanf("");
+        const uint32_t xh = bf16_bits(ux), zh = bf16_bits(uz), nh = bf16_bits(nou);
+        const uint32_t xl = bf16_bits(ux - __uint_as_float(xh)), zl = bf16_bits(uz - __uint_as_float(zh)), nl = bf16_bits(nou - __uint_as_float(nh));
+        uint32_t L0 = (xh >> 16) | xh, L1 = (xl >> 16) | zh, H0 = (zh >> 16) | zl, H1 = (nh >> 16) | nl;
+        swap_halves(L0, H0); swap_halves(L1, H1);
+        mb1 = __builtin_bit_cast(bf16x4, make_uint2(L0, L1));
+        mb2 = __builtin_bit_cast(bf16x4, make_uint2(H0, H1));
+        asm volatile("" : "+v"(threshold88));
+    }
+    auto filter_mfma = [&](uint2 araw) -> uint32_t {
+        const bf16x4 a = __builtin_bit_cast(bf16x4, araw);
+        f16acc zero;
+#pragma unroll
+        for (int v = 0; v < 16; ++v) zero[v] = 0.0f;
+        const f16acc d1 = __builtin_amdgcn_mfma_f32_32x32x8bf16_1k(a, mb1, zero, 0, 0, 0);
+        const f16acc d2 = __builtin_amdgcn_mfma_f32_32x32x8bf16_1k(a, mb2, zero, 0, 0, 0);
+        float acc1 = 128.0f, acc2 = 128.0f;
+        // (the [0, 1] median is folded into the FMA's clamp modifier; written this way, not as inline assembly, the compiler
+        // sees the read of a matrix result and keeps the wait states it needs)
+#pragma unroll
+        for (int v = 0; v < 16; ++v) acc1 = fmaf(acc1, 2.0f, __builtin_amdgcn_fmed3f(fmaf(-d1[v], d1[v], threshold88), 0.0f, 1.0f));
+#pragma unroll
+        for (int v = 0; v < 16; ++v) acc2 = fmaf(acc2, 2.0f, __builtin_amdgcn_fmed3f(fmaf(-d2[v], d2[v], threshold88), 0.0f, 1.0f));
+        uint32_t m1 = __float_as_uint(acc1), m2 = __float_as_uint(acc2);
+        swap_halves(m1, m2);
+        return __builtin_amdgcn_perm(m1, m2, 0x05040100u);       // (low half of m1) << 16 | low half of m2
+    };
 
     T.mark(1);
     // Super-chunks of up to 16 mask words (512 spheres).  The filter only stores each word and notes
@@ -280,41 +347,58 @@ __device__ __forceinline__ void closest_hit(const RayD& ray, float tmin, const S
         // one flag word covers 16 chunks (512 spheres); this super-chunk's share of it, bit (kSuperChunkWords - 1 - w): word w is stored normalised
         constexpr uint32_t kAllWords = (1u << kSuperChunkWords) - 1u;
         const int flag_shift = kSuperChunkWords * (16 / kSuperChunkWords - 1 - ((sbase / (32 * kSuperChunkWords)) % (16 / kSuperChunkWords)));
-        const uint32_t normalised = kPlane ? (force_k[((sw.n_pad + 31) >> 5) + (sbase >> 9)] >> flag_shift) & kAllWords : 0u;
+        const uint32_t normalised = kPlane && !kMfma ? (force_k[((sw.n_pad + 31) >> 5) + (sbase >> 9)] >> flag_shift) & kAllWords : 0u;
         const int full_words = (send - sbase) >> 5;
         // two loops with one body each (a single loop choosing between the two unrolled bodies per word makes the
         // register allocator spill twenty registers)
-        if (normalised != 0u) {
-            for (int w = 0; w < full_words; ++w) {
-                if (((normalised >> (kSuperChunkWords - 1 - w)) & 1u) == 0u) continue;
-                const uint32_t cand = filter_norm(sbase + 32 * w, threshold88);
+        if constexpr (kMfma) {
+            // one matrix-pipe chunk per mask word, the operand of the next chunk requested before this one is worked on
+            const int words_here = (send - sbase + 31) >> 5;
+            const uint2* ap = (kLds ? lds.arec : sw.arec) + (size_t)(sbase >> 5) * 64 + (threadIdx.x & 63u);
+            uint2 a_next = ap[0];
+            uint32_t seen = 0u;
+            for (int w = 0; w < words_here; ++w) {
+                const uint2 a_now = a_next;
+                if (w + 1 < words_here) a_next = ap[(w + 1) * 64];
+                const uint32_t cand = filter_mfma(a_now);
                 mask_words[w * 64] = cand;
-                nz |= cand != 0u ? 0x80000000u >> w : 0u;
+                seen = seen + seen + (cand != 0u ? 1u : 0u);
             }
-        }
-        if (normalised != (kAllWords & ~(kAllWords >> full_words))) {
-            for (int w = 0; w < full_words; ++w) {
-                if (((normalised >> (kSuperChunkWords - 1 - w)) & 1u) != 0u) continue;
-                const uint32_t cand = filter_bits(sbase + 32 * w, std::integral_constant<int, 32>());
-                mask_words[w * 64] = cand;
-                nz |= cand != 0u ? 0x80000000u >> w : 0u;
+            nz = seen << (32 - words_here);
+            words = words_here; base = send;
+        } else {
+            if (normalised != 0u) {
+                for (int w = 0; w < full_words; ++w) {
+                    if (((normalised >> (kSuperChunkWords - 1 - w)) & 1u) == 0u) continue;
+                    const uint32_t cand = filter_norm(sbase + 32 * w, threshold88);
+                    mask_words[w * 64] = cand;
+                    nz |= cand != 0u ? 0x80000000u >> w : 0u;
+                }
             }
-        }
-        words = full_words; base = sbase + 32 * full_words;
-        if (base < send) {         // tail: 8, 16 or 24 records
-            const int got = send - base;
-            const uint32_t cand = got == 8 ? filter_bits(base, std::integral_constant<int, 8>())
-                                : got == 16 ? filter_bits(base, std::integral_constant<int, 16>()) : filter_bits(base, std::integral_constant<int, 24>());
-            base = send;
-            mask_words[words * 64] = cand;
-            nz |= cand != 0u ? 0x80000000u >> words : 0u;
-            ++words;
+            if (normalised != (kAllWords & ~(kAllWords >> full_words))) {
+                for (int w = 0; w < full_words; ++w) {
+                    if (((normalised >> (kSuperChunkWords - 1 - w)) & 1u) != 0u) continue;
+                    const uint32_t cand = filter_bits(sbase + 32 * w, std::integral_constant<int, 32>());
+                    mask_words[w * 64] = cand;
+                    nz |= cand != 0u ? 0x80000000u >> w : 0u;
+                }
+            }
+            words = full_words; base = sbase + 32 * full_words;
+            if (base < send) {         // tail: 8, 16 or 24 records
+                const int got = send - base;
+                const uint32_t cand = got == 8 ? filter_bits(base, std::integral_constant<int, 8>())
+                                    : got == 16 ? filter_bits(base, std::integral_constant<int, 16>()) : filter_bits(base, std::integral_constant<int, 24>());
+                base = send;
+                mask_words[words * 64] = cand;
+                nz |= cand != 0u ? 0x80000000u >> words : 0u;
+                ++words;
+            }
         }
         // spheres the plane filter does not judge (none in ordinary scenes): their bits are added here, outside the hot loop
         if (kPlane && sw.n_forced > 0) {
             for (int w = 0; w < words; ++w) {
                 const uint32_t f = force_k[(sbase >> 5) + w];
-                if (f != 0u) { mask_words[w * 64] |= f; nz |= 0x80000000u >> w; }
+                if (f != 0u && active) { mask_words[w * 64] |= f; nz |= 0x80000000u >> w; }
             }
         }
         T.mark(1);

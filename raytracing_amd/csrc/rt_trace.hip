@@ -27,6 +27,7 @@ struct TraceArgs {
     const uint32_t* force; int n_forced;   // per 32 spheres: the ones the plane filter does not judge (see closest_hit), and their number
     float plane_s0, plane_rmin;   // plane filter: constant part of the per-ray slack, smallest R_i
     const float4* frec;      // discriminant-filter records (cx, cy, cz, |c|^2 - r^2 - slack), padded to a multiple of 8
+    const uint2* arec; float mfma_g;       // matrix-pipe form of the plane filter: A operands per chunk of 32 spheres, per-ray allowance (closest_hit)
     const float4* geom; const float4* mat; const Aux* aux; int n, n_pad;
     CameraD cam;
     int width, height, max_depth; float tmin;
@@ -273,22 +274,27 @@ __global__ void __launch_bounds__(256) k_tile_class_from_lists(const uint32_t* l
 #endif
 constexpr bool kWidePhilox = RT_WIDE_PHILOX != 0;     // the staging phase of k_trace has the registers for 64-bit products
 constexpr int kUnresolved = -2;             // staging row 9: the staged ray is the camera ray itself (no list for its tile), not the path's second ray
-template <bool kLds, bool kPlane, bool kBvh = false>
-__global__ void __launch_bounds__(kTraceBlock) RT_TRACE_WAVES(kBvh, kLds) k_trace(const TraceArgs a)
+template <bool kLds, bool kPlane, bool kBvh = false, bool kMfma = false>
+__global__ void __launch_bounds__(trace_block(kMfma)) RT_TRACE_WAVES(kBvh, kLds) k_trace(const TraceArgs a)
 {
+    constexpr int kTraceBlock = trace_block(kMfma);       // (shadows the 512 of the other kernels inside this one)
     extern __shared__ float4 smem[];
     // LDS: [geom n][mat n][aux n (8 B)] when kLds; geom in the packed form of ExactLds (centre, discriminant-filter constant)
-    // for the sweep, in the plain form (centre, r*r) for the hierarchy walk.
+    // for the sweep, in the plain form (centre, r*r) for the hierarchy walk.  With the matrix-pipe filter its A operands follow
+    // (512 bytes per chunk of 32 spheres).
     float4* s_geom = smem;
     float4* s_mat = smem + (kLds ? a.n : 0);
     Aux* s_aux = reinterpret_cast<Aux*>(smem + (kLds ? 2 * a.n : 0));
+    const int a_words = kLds && kMfma ? ((a.n + 31) >> 5) * 64 : 0;       // uint2 entries
+    uint2* s_arec = reinterpret_cast<uint2*>(reinterpret_cast<char*>(smem) + (kLds ? (size_t)a.n * kLdsBytesPerSphere : 0));
     if (kLds) {
         for (int i = threadIdx.x; i < a.n; i += kTraceBlock) { const float4 g = a.geom[i]; s_geom[i] = make_float4(g.x, g.y, g.z, kBvh ? g.w : a.frec[i].w); s_mat[i] = a.mat[i]; s_aux[i] = a.aux[i]; }
+        for (int i = threadIdx.x; i < a_words; i += kTraceBlock) s_arec[i] = a.arec[i];
     }
-    const ExactLds exact_lds{ s_geom, s_aux, nullptr };
+    ExactLds exact_lds{ s_geom, s_aux, nullptr }; exact_lds.arec = s_arec;
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     // Per-lane filter masks of one super-chunk: word w of lane l at mask_words[w * 64] (lanes contiguous).
-    char* lds_after_scene = reinterpret_cast<char*>(smem) + (kLds ? (size_t)a.n * kLdsBytesPerSphere : 0);
+    char* lds_after_scene = reinterpret_cast<char*>(smem) + (kLds ? (size_t)a.n * kLdsBytesPerSphere : 0) + (size_t)a_words * sizeof(uint2);
     // (In RT_MODE_BVH the same area holds each lane's stack of pending nodes instead.)
     constexpr int kWordsPerLane = kBvh ? kBvhStack : kSuperChunkWords;
     uint32_t* mask_words = reinterpret_cast<uint32_t*>(lds_after_scene) + (size_t)wave * kWordsPerLane * 64 + lane;
@@ -314,7 +320,7 @@ __global__ void __launch_bounds__(kTraceBlock) RT_TRACE_WAVES(kBvh, kLds) k_trac
     SecTimer T; T.start();
     ItemGeometry ig; ig.width = a.width; ig.height = a.height; ig.band_rows = a.band_rows; ig.band_first = a.band_first; ig.band_step = a.band_step;
     ig.owned_rows = a.owned_rows; ig.tiles_x = a.tiles_x; ig.Q = a.Q; ig.s_begin = a.s_begin; ig.s_count = a.s_count; ig.tile_order = a.tile_order;
-    SweepScene sw; sw.frec = a.frec; sw.prec = a.prec; sw.force = a.force; sw.n_forced = a.n_forced; sw.plane_s0 = a.plane_s0; sw.plane_rmin = a.plane_rmin; sw.geom = a.geom; sw.n = a.n; sw.n_pad = a.n_pad;
+    SweepScene sw; sw.arec = a.arec; sw.mfma_g = a.mfma_g; sw.frec = a.frec; sw.prec = a.prec; sw.force = a.force; sw.n_forced = a.n_forced; sw.plane_s0 = a.plane_s0; sw.plane_rmin = a.plane_rmin; sw.geom = a.geom; sw.n = a.n; sw.n_pad = a.n_pad;
 
 #ifdef RT_WAVE_TIMELINE
     const unsigned long long t_enter = __builtin_amdgcn_s_memrealtime(); unsigned long long t_dry = 0, trips_dry = 0, sparse_trips = 0, sparse_ticks = 0, t_trip = 0, t_first_sweep = 0, t_first_done = 0; bool was_sparse = false;
@@ -488,6 +494,7 @@ __global__ void __launch_bounds__(kTraceBlock) RT_TRACE_WAVES(kBvh, kLds) k_trac
 #endif
         if (kBvh) { if (active) closest_hit_bvh<kLds>(ray, a.tmin, a.bvh, exact_lds, mask_words, closest, hit); }
         else if (__popcll(live) <= kFewPaths) closest_hit_few<kLds>(ray, a.tmin, sw, exact_lds, live, lane, closest, hit);
+        else if constexpr (kMfma) closest_hit<kLds, true, true, true>(ray, a.tmin, sw, exact_lds, mask_words, closest, hit, T, active);     // the whole wave enters
         else if (active) closest_hit<kLds, kPlane, true>(ray, a.tmin, sw, exact_lds, mask_words, closest, hit, T);
         rays += (uint32_t)__popcll(live); misses += (uint32_t)__popcll(__ballot(active && hit < 0));
         if (active) {
@@ -559,6 +566,7 @@ namespace {
 using TraceKernel = void (*)(const TraceArgs);
 TraceKernel trace_kernel(const TracePlan& t)
 {
+    if (t.mfma) return t.lds ? k_trace<true, true, false, true> : k_trace<false, true, false, true>;
     if (t.bvh) return t.lds ? k_trace<true, true, true> : k_trace<false, true, true>;
     if (t.lds) return t.plane ? k_trace<true, true> : k_trace<true, false>;
     return t.plane ? k_trace<false, true> : k_trace<false, false>;
@@ -615,17 +623,19 @@ int trace_prepare(rt_context* ctx, const RenderFrame& f, TracePlan* plan)
     t.lds = ctx->n <= kMaxLdsSpheres;
     t.plane = ctx->plane_filter;
     t.bvh = p->mode == RT_MODE_BVH;
-    t.shmem = (t.lds ? (size_t)ctx->n * kLdsBytesPerSphere : 0) + (size_t)(kTraceBlock / 64) * (t.bvh ? kBvhStack : kSuperChunkWords) * 64 * sizeof(uint32_t);
-    int& bpc = ctx->trace_blocks_per_cu[t.bvh ? (t.lds ? 5 : 4) : (t.lds ? 1 : 0) + (t.plane ? 2 : 0)];
+    t.mfma = !t.bvh && t.plane && ctx->mfma_filter;
+    t.block = trace_block(t.mfma);
+    t.shmem = (t.lds ? (size_t)ctx->n * kLdsBytesPerSphere + (t.mfma ? (size_t)((ctx->n + 31) / 32) * 512 : 0) : 0) + (size_t)(t.block / 64) * (t.bvh ? kBvhStack : kSuperChunkWords) * 64 * sizeof(uint32_t);
+    int& bpc = ctx->trace_blocks_per_cu[t.mfma ? (t.lds ? 7 : 6) : t.bvh ? (t.lds ? 5 : 4) : (t.lds ? 1 : 0) + (t.plane ? 2 : 0)];
     if (bpc == 0) {
         int nb = 0;
-        hipError_t e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, trace_kernel(t), kTraceBlock, t.shmem);
+        hipError_t e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, trace_kernel(t), t.block, t.shmem);
         if (e != hipSuccess) return fail(ctx, RT_ERR_HIP, "occupancy query for the render kernel (%zu bytes of LDS per block) failed: %s", t.shmem, hipGetErrorString(e));
         if (nb <= 0) return fail(ctx, RT_ERR_TOO_LARGE, "the render kernel does not fit a compute unit with %zu bytes of LDS per block (%d spheres)", t.shmem, ctx->n);
         bpc = nb;
     }
     t.blocks_per_cu = bpc;
-    const size_t lanes = (size_t)ctx->num_cu * bpc * kTraceBlock;
+    const size_t lanes = (size_t)ctx->num_cu * bpc * t.block;
     if (ctx->stacks_lanes < lanes) {
         HIP_TRY(ctx, hipStreamSynchronize(st));
         (void)hipFree(ctx->d_stacks); ctx->d_stacks = nullptr; ctx->stacks_lanes = 0;
@@ -664,7 +674,7 @@ int trace_batch(rt_context* ctx, const RenderFrame& f, const TracePlan& t, const
 {
     const rt_params* p = f.p;
     TraceArgs a;
-    a.prec = ctx->d_prec; a.force = ctx->d_force; a.n_forced = ctx->n_forced; a.plane_s0 = ctx->plane_s0; a.plane_rmin = ctx->plane_rmin; a.frec = ctx->d_frec; a.geom = ctx->d_geom; a.mat = ctx->d_mat; a.aux = ctx->d_aux; a.n = ctx->n; a.n_pad = ctx->n_pad; a.cam = ctx->cam;
+    a.arec = ctx->d_arec; a.mfma_g = ctx->mfma_g; a.prec = ctx->d_prec; a.force = ctx->d_force; a.n_forced = ctx->n_forced; a.plane_s0 = ctx->plane_s0; a.plane_rmin = ctx->plane_rmin; a.frec = ctx->d_frec; a.geom = ctx->d_geom; a.mat = ctx->d_mat; a.aux = ctx->d_aux; a.n = ctx->n; a.n_pad = ctx->n_pad; a.cam = ctx->cam;
     a.width = p->width; a.height = p->height; a.max_depth = p->max_depth; a.tmin = p->tmin;
     a.k0 = (uint32_t)p->seed; a.k1 = (uint32_t)(p->seed >> 32);
     a.band_rows = p->band_rows; a.band_first = p->band_first; a.band_step = p->band_step; a.owned_rows = f.owned;
@@ -675,7 +685,7 @@ int trace_batch(rt_context* ctx, const RenderFrame& f, const TracePlan& t, const
     a.tile_lists = ctx->primary_lists ? ctx->d_tile_lists : nullptr;
     a.bvh.nodes = ctx->d_bvh_nodes; a.bvh.leaf_index = ctx->d_bvh_leaf; a.bvh.big = ctx->d_bvh_big; a.bvh.n_big = ctx->bvh_n_big; a.bvh.geom = ctx->d_geom;
     // small jobs take smaller chunks so that every resident wave gets several (tail balance)
-    const uint64_t resident_waves = (uint64_t)ctx->num_cu * t.blocks_per_cu * (kTraceBlock / 64);
+    const uint64_t resident_waves = (uint64_t)ctx->num_cu * t.blocks_per_cu * (t.block / 64);
 #ifndef RT_CHUNK_DIV
 #define RT_CHUNK_DIV 16
 #endif
@@ -685,11 +695,11 @@ int trace_batch(rt_context* ctx, const RenderFrame& f, const TracePlan& t, const
     a.chunk_items = (int)(chunk < 64 ? 64 : (chunk > (uint64_t)kChunkItems ? (uint64_t)kChunkItems : chunk));
     a.resident_waves = (uint32_t)resident_waves;
     { const uint64_t m = floor_items < 64 ? 64 : floor_items; a.min_chunk_items = (uint32_t)(m < (uint64_t)a.chunk_items ? m : (uint64_t)a.chunk_items); }
-    const uint64_t want_blocks = ((uint64_t)a.total_items + (uint64_t)a.chunk_items * (kTraceBlock / 64) - 1) / ((uint64_t)a.chunk_items * (kTraceBlock / 64));
+    const uint64_t want_blocks = ((uint64_t)a.total_items + (uint64_t)a.chunk_items * (t.block / 64) - 1) / ((uint64_t)a.chunk_items * (t.block / 64));
     const uint64_t cap_blocks = (uint64_t)ctx->num_cu * t.blocks_per_cu;
-    const dim3 grid((unsigned)(want_blocks < cap_blocks ? want_blocks : cap_blocks)), block(kTraceBlock);
+    const dim3 grid((unsigned)(want_blocks < cap_blocks ? want_blocks : cap_blocks)), block(t.block);
     // the first chunk of every launched wave is implied by its index; the counter hands out what follows
-    HIP_TRY(ctx, hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(ctx->d_work), (int)(grid.x * (unsigned)(kTraceBlock / 64) * (unsigned)a.chunk_items), 1, f.st));
+    HIP_TRY(ctx, hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(ctx->d_work), (int)(grid.x * (unsigned)(t.block / 64) * (unsigned)a.chunk_items), 1, f.st));
     hipLaunchKernelGGL(trace_kernel(t), grid, block, t.shmem, f.st, a);
     HIP_TRY(ctx, hipGetLastError());
     return RT_OK;
