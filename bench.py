@@ -10,6 +10,11 @@ relays their output; under an existing launcher (RANK / WORLD_SIZE set) it is on
 One step = one render of the whole image: each rank renders its interleaved row bands (scene and camera
 replicated, resident in HBM before the timed region) and, for N > 1, one RCCL gather assembles the rows on
 rank 0.  Total work is fixed as N grows ("strong" scaling).  Rank 0 prints one JSON line.
+
+The timed path is the brute-force one: EVERY ray, camera rays included, is tested against every sphere
+(HittableList::Hit, hittablelist.cpp:21-29, over Sphere::Hit, sphere.cpp:15-52), so `value` and `roofline`
+describe that loop.  The library's shortcut for camera rays (per-tile sphere lists, rt_set_camera_ray_lists)
+is measured beside it, outside the timed region, as the `beyond_brute_force` object of the line.
 """
 import argparse
 import ctypes as C
@@ -144,7 +149,10 @@ def parse_args(argv):
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--workload", default="c3", choices=sorted(WORKLOADS))
     ap.add_argument("--spp", type=int, default=0, help="override samples per pixel")
-    ap.add_argument("--no-sweep-only", action="store_true", help="skip the extra renders with camera rays swept like every other ray (the sweep_only object of the line)")
+    ap.add_argument("--no-beyond", "--no-sweep-only", dest="no_beyond", action="store_true",
+                    help="skip the extra renders with camera rays through per-tile sphere lists (the beyond_brute_force object of the line)")
+    ap.add_argument("--camera-ray-lists", action="store_true", help="time the path with the camera-ray shortcut instead of the brute-force one (not the headline)")
+    ap.add_argument("--force-dist", action="store_true", help="N = 1: still create the RCCL process group (one rank) and run the gather and the reductions through it")
     ap.add_argument("--band-rows", type=int, default=0, help="rows per band (0 = 8 on one GPU, 1 on several)")
     ap.add_argument("--seed", type=int, default=0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -215,21 +223,24 @@ def setup_scene(rt, scene_name, width, height):
 
 
 def roofline_block(args, n_spheres, rays_per_launch, kernel_ms, prof):
-    """The FP32 vector-ALU roofline of the dominant kernel.  `achieved` and `frac` price the ALGORITHMIC work: the reference tests
-    every sphere against every ray at 18 flop per test; the kernel reaches the same answers with fewer operations (camera rays
-    against the short sphere list of their tile, every other ray through a 3-4 FMA filter and the full test on the survivors),
-    so `achieved` says how fast the reference's work gets done and is not what the ALUs execute -- it can exceed the peak.
-    `executed_*` is that other number, from the profiled instruction counters; the `sweep_only` object of the line is the same
-    workload with every ray, camera rays included, swept over all spheres."""
+    """The FP32 vector-ALU roofline of the dominant kernel, k_trace on the brute-force path: every ray against every sphere.
+    `achieved` prices each ray-sphere test at the reference's 18 flop (sphere.cpp:17-25) plus 150 flop per ray for hit record
+    and scatter: rays x (18 x spheres + 150) / kernel time.  The kernel makes every one of those tests, but as a conservative
+    filter (the pair's dot product on the bf16 matrix pipe, verdict and accumulate on the vector ALU) followed by the reference's
+    own arithmetic on the few survivors, so it executes fewer FP32 operations than it is credited with: `executed_*`, from the
+    profiled instruction counters, is what the vector ALU did."""
     flop_per_ray = FLOP_PER_TEST * n_spheres + FLOP_PER_RAY_EXTRA
     achieved = rays_per_launch * flop_per_ray / (kernel_ms * 1e-3) / 1e12
     block = {"bound": "valu", "achieved": achieved, "peak": PEAK_FP32_VALU_TFLOPS, "unit": "TFLOP/s", "frac": achieved / PEAK_FP32_VALU_TFLOPS,
-             "frac_is": "algorithmic-equivalent: rays x (18 x spheres + 150) flop per launch / kernel time / peak; the kernel executes fewer operations than that "
-                        "(camera rays meet only the spheres on their tile's list), see executed_frac and sweep_only",
+             "frac_is": "rays x (18 x spheres + 150) flop per launch / kernel time / peak, every ray tested against every sphere (brute force); "
+                        "executed_frac is what the vector ALU executed",
              "peak_sustained_measured": SUSTAINED_FP32_FMA_TFLOPS, "frac_of_sustained": achieved / SUSTAINED_FP32_FMA_TFLOPS,
              "kernel": {"megakernel": "k_trace", "wavefront": "k_wf_intersect + k_wf_shade", "pixel": "k_render_mega", "bvh": "k_trace (hierarchy walk)"}[args.mode],
              "flop_per_ray": flop_per_ray, "traffic": None, "executed_achieved": None, "executed_frac": None,
-             "note": "FP32 vector-ALU bound (HBM traffic and MFMA are not on this path)"}
+             "note": "FP32 vector-ALU bound: the pair test's dot product runs on the bf16 matrix pipe (2 of ~7 SIMD cycles per sphere and wave), "
+                     "verdict, accumulate, exact passes and shading on the vector ALU; HBM traffic is small"}
+    if args.camera_ray_lists:
+        block["frac_is"] = "NOT a brute-force figure: camera rays met only the spheres on their tile's list, so the flop count overstates the work done"
     usable = prof is not None and args.mode == "megakernel" and args.workload in ("c1", "c3", "c4") and prof.get("spheres") == n_spheres
     if usable:
         block["traffic"] = prof["hbm_bytes_per_ray"] * rays_per_launch
@@ -282,7 +293,16 @@ def main(argv=None):
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     backend = None
-    if world > 1:
+    use_dist = world > 1 or args.force_dist
+    if use_dist:
+        if world == 1:
+            # a one-rank group of its own: RCCL is loaded, the gather and the reductions below run through it
+            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+            if "MASTER_PORT" not in os.environ:
+                with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as sk:
+                    sk.bind(("127.0.0.1", 0))
+                    os.environ["MASTER_PORT"] = str(sk.getsockname()[1])
+            os.environ.setdefault("RANK", "0"); os.environ.setdefault("WORLD_SIZE", "1")
         backend = "gloo" if args.rehearse_on_one_gpu else "nccl"
         if args.rehearse_on_one_gpu:
             dist.init_process_group("gloo")
@@ -292,7 +312,7 @@ def main(argv=None):
     scene_name, width, height, spp = WORKLOADS[args.workload]
     if args.spp:
         spp = args.spp
-    rt = R.Renderer(local_rank)
+    rt = R.Renderer(local_rank, camera_ray_lists=bool(args.camera_ray_lists))
     n_spheres = setup_scene(rt, scene_name, width, height)
 
     band = args.band_rows
@@ -308,7 +328,7 @@ def main(argv=None):
     # (a NaN radiance prints as -2147483648), and 12 B per pixel is 1.4 MB per peer link on config 3 and 12.4 MB on config 4
     # (< 0.1 ms at 153 GB/s per xGMI link), so the assembled image stays identical to the single-GPU one in every case.
     out = torch.zeros((pad, width, 3), dtype=torch.int32, device=dev)
-    idx = rdist.row_index(height, band, world, dev) if world > 1 else None
+    idx = rdist.row_index(height, band, world, dev) if use_dist else None
     stream = torch.cuda.current_stream().cuda_stream
 
     kernel_ms, rays_per_step, gather_ms = [], [], []
@@ -316,39 +336,39 @@ def main(argv=None):
 
     def step(record):
         rt.render_device(p, d_irgb=out.data_ptr(), stream=stream)
-        if world > 1:
+        if use_dist:
             ev_a.record()
         if args.rehearse_on_one_gpu and world > 1:
             img = rdist.gather_rows(out.cpu(), height, band, rank, world, src_index=idx.cpu())
         else:
-            img = rdist.gather_rows(out, height, band, rank, world, src_index=idx)
-        if world > 1:
+            img = rdist.gather_rows(out, height, band, rank, world, src_index=idx, force_collective=use_dist)
+        if use_dist:
             ev_b.record()
         rays, ms = rt.stats()                 # waits for this rank's kernels (HIP events on `stream`)
         if record:
             kernel_ms.append(ms)
             rays_per_step.append(rays)
-            if world > 1:
+            if use_dist:
                 ev_b.synchronize()
                 gather_ms.append(ev_a.elapsed_time(ev_b))
         return img
 
     for _ in range(args.warmup):
         step(False)
-    if world > 1:
+    if use_dist:
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for _ in range(args.steps):
         img = step(True)
     torch.cuda.synchronize()
-    if world > 1:
+    if use_dist:
         dist.barrier()
     elapsed = time.perf_counter() - t0
 
     t = torch.tensor([elapsed, float(sum(rays_per_step)), float(np.mean(kernel_ms)), float(np.max(kernel_ms))], dtype=torch.float64, device=dev)
     per_rank_kernel_ms = [float(np.mean(kernel_ms))]
-    if world > 1:
+    if use_dist:
         if args.rehearse_on_one_gpu:
             t = t.cpu()
         tmax = t.clone(); dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
@@ -374,10 +394,11 @@ def main(argv=None):
                        if scene_name == "final" else (f"{args.workload}: synthetic {n_spheres}-sphere grid scene, {width}x{height}, {spp} spp, max depth 50"
                                                       if scene_name == "grid20k" else f"{args.workload}: three-sphere material scene, {width}x{height}, {spp} spp"),
                        "band_rows": band, "partition": f"interleaved row bands over {world} GPU(s), one RCCL gather to rank 0" if world > 1 else "single GPU",
-                       "seed": args.seed, "mode": args.mode},
+                       "seed": args.seed, "mode": args.mode,
+                       "camera_rays": "per-tile sphere lists (shortcut)" if args.camera_ray_lists else "swept over all spheres like every other ray (brute force)"},
             "msamples_per_s": samples / elapsed / 1e6, "rays_per_sample": total_rays / samples,
             "kernel_ms_mean": kms_mean, "kernel_ms_max": kms_max,
-            "ranks_reported_by_backend": dist.get_world_size() if world > 1 else 1, "backend": backend,
+            "ranks_reported_by_backend": dist.get_world_size() if use_dist else 1, "backend": (dist.get_backend() if use_dist else None),
             "kernel_ms_per_rank": per_rank_kernel_ms,
             "gather_ms_rank0": float(np.mean(gather_ms)) if gather_ms else None,
             "gather_bytes_per_step": int(pad * width * 3 * 4 * (world - 1)) if world > 1 else 0,
@@ -423,12 +444,10 @@ def main(argv=None):
             line["config1"] = {"workload": f"c1: RTOW final random-spheres scene ({n_spheres} spheres), {width}x{height}, 10 spp, max depth 50",
                                "ms_per_step": wall1, "kernel_ms_mean": km, "kernel_ms_min": float(np.min(ms1)), "mrays_per_s": rays1 / (wall1 * 1e-3) / 1e6,
                                "roofline_frac": fr, "steps": 20}
-        if world == 1 and args.mode == "megakernel" and not args.no_sweep_only and not os.environ.get("RT_AMD_PRIMARY"):
-            # The same workload with camera rays swept over all spheres like every other ray (RT_AMD_PRIMARY=sweep is read when a
-            # context is created): what the sweep alone delivers, outside the timed region above.
-            os.environ["RT_AMD_PRIMARY"] = "sweep"
-            rt2 = R.Renderer(local_rank)
-            del os.environ["RT_AMD_PRIMARY"]
+        if world == 1 and args.mode == "megakernel" and not args.no_beyond and not args.camera_ray_lists:
+            # Beyond brute force, outside the timed region: the same workload on a second context whose camera rays find their
+            # first hit over per-tile sphere lists (rt_set_camera_ray_lists) instead of the sweep.  Same image, fewer tests.
+            rt2 = R.Renderer(local_rank, camera_ray_lists=True)
             setup_scene(rt2, scene_name, width, height)
             rt2.render_device(p, d_irgb=out.data_ptr(), stream=stream); rt2.stats()
             ms2, rays2 = [], 0
@@ -440,13 +459,14 @@ def main(argv=None):
                 ms2.append(m)
             torch.cuda.synchronize()
             wall2 = (time.perf_counter() - t2) / len(ms2) * 1e3
-            line["sweep_only"] = {"what": "every ray, camera rays included, through the filter + exact sweep over all spheres (RT_AMD_PRIMARY=sweep), same image",
-                                  "ms_per_step": wall2, "kernel_ms_mean": float(np.mean(ms2)), "mrays_per_s": rays2 / (wall2 * 1e-3) / 1e6,
-                                  "roofline_frac": rays2 * (FLOP_PER_TEST * n_spheres + FLOP_PER_RAY_EXTRA) / (float(np.mean(ms2)) * 1e-3) / 1e12 / PEAK_FP32_VALU_TFLOPS,
-                                  "image_checksum_equal": int(out.to(torch.int64).sum().item()) == checksum, "steps": len(ms2)}
+            line["beyond_brute_force"] = {"what": "camera rays (38 % of all rays) against the short sphere list of their 8x8 tile instead of all spheres; every other ray swept as in the headline; same image",
+                                          "ms_per_step": wall2, "kernel_ms_mean": float(np.mean(ms2)), "mrays_per_s": rays2 / (wall2 * 1e-3) / 1e6,
+                                          "image_checksum_equal": int(out.to(torch.int64).sum().item()) == checksum, "rays_equal": rays2 == int(my_rays), "steps": len(ms2)}
             rt2.close()
+        if line["roofline"].get("executed_frac") is not None:
+            assert line["roofline"]["executed_frac"] <= 1.0, "executed FP32 rate above the peak: the profile summary under profiles/ does not belong to this kernel"
         print(json.dumps(line), flush=True)
-    if world > 1:
+    if use_dist:
         dist.destroy_process_group()
 
 

@@ -98,6 +98,13 @@ int rt_upload_scene(rt_context *ctx, int n, const float *cx, const float *cy, co
 /* Replaces reading the Camera object inside GetRay (camera.cpp:46-53). */
 int rt_set_camera(rt_context *ctx, const rt_camera_pod *cam);
 
+/* Camera rays (the first Color() call of a sample, main.cpp:129-133) can take a shortcut that is NOT part of the brute-force
+ * loop of hittablelist.cpp:21-29: with `enabled` != 0 the megakernel finds their closest hit over a per-tile list of the
+ * spheres the tile's camera rays can reach (built every call, see rt_test_tile_lists) instead of sweeping all spheres.  Same
+ * image and counters either way.  A new context starts with the shortcut enabled unless the environment variable
+ * RT_AMD_PRIMARY is "sweep"; enabled = 0 makes every ray, camera rays included, go through the sweep over all spheres. */
+int rt_set_camera_ray_lists(rt_context *ctx, int enabled);
+
 /* ---- render: the loop body of main.cpp:118-141 ---------------------------------------- */
 /* Number of image rows / pixels the call described by p produces (0 on invalid p). */
 int64_t rt_owned_rows(const rt_params *p);

@@ -12,7 +12,7 @@ MODE_MEGAKERNEL, MODE_WAVEFRONT, MODE_PIXEL, MODE_BVH = 0, 1, 2, 3
 LAMBERTIAN, METAL, DIELECTRIC = 0, 1, 2
 
 # every symbol include/rt_amd.h declares
-EXPORTS = ["rt_device_count", "rt_create", "rt_destroy", "rt_last_error", "rt_upload_scene", "rt_set_camera",
+EXPORTS = ["rt_device_count", "rt_create", "rt_destroy", "rt_last_error", "rt_upload_scene", "rt_set_camera", "rt_set_camera_ray_lists",
            "rt_owned_rows", "rt_owned_pixels", "rt_render_device", "rt_render_stats", "rt_render_counters", "rt_render", "rt_render_multi",
            "rt_scene_grid", "rt_build_hierarchy", "rt_format_ppm", "rt_write_ppm", "rt_write_ppm_binary", "rt_encode_ppm_device", "rt_encode_ppm_device_noalloc", "rt_write_ppm_device", "rt_test_sphere_hit", "rt_test_scatter", "rt_test_get_ray",
            "rt_test_helpers", "rt_test_tile_lists", "rt_test_philox"]
@@ -86,6 +86,7 @@ def load_library():
     L.rt_last_error.restype = C.c_char_p
     L.rt_upload_scene.argtypes = [vp, C.c_int, fp, fp, fp, fp, ip, fp, fp]
     L.rt_set_camera.argtypes = [vp, C.POINTER(CameraPod)]
+    L.rt_set_camera_ray_lists.argtypes = [vp, C.c_int]
     L.rt_owned_rows.argtypes = [C.POINTER(Params)]
     L.rt_owned_rows.restype = C.c_int64
     L.rt_owned_pixels.argtypes = [C.POINTER(Params)]
@@ -176,7 +177,9 @@ class Camera:
 class Renderer:
     """One context on one GPU: upload a flattened sphere list and a camera, then render."""
 
-    def __init__(self, device=0):
+    def __init__(self, device=0, camera_ray_lists=None):
+        """camera_ray_lists: None keeps the library's default (on, unless RT_AMD_PRIMARY=sweep); False sends camera rays through the
+        brute-force sweep like every other ray; True finds their first hit over per-tile sphere lists."""
         self._L = load_library()
         self._ctx = C.c_void_p()
         rc = self._L.rt_create(device, C.byref(self._ctx))
@@ -184,6 +187,13 @@ class Renderer:
             raise RtError(rc, self._L.rt_last_error(None).decode())
         self.device = device
         self.n_spheres = 0
+        self.camera_ray_lists = None          # None: the library's default, whatever the environment made it
+        if camera_ray_lists is not None:
+            self.set_camera_ray_lists(camera_ray_lists)
+
+    def set_camera_ray_lists(self, enabled):
+        self._check(self._L.rt_set_camera_ray_lists(self._ctx, 1 if enabled else 0))
+        self.camera_ray_lists = bool(enabled)
 
     def close(self):
         if getattr(self, "_ctx", None):

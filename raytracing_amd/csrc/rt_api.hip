@@ -78,6 +78,7 @@ void rt_destroy(rt_context* ctx)
     (void)hipFree(ctx->wf_stacks); (void)hipFree(ctx->wf_q[0]); (void)hipFree(ctx->wf_q[1]); (void)hipFree(ctx->wf_n);
     if (ctx->ev0) (void)hipEventDestroy(ctx->ev0);
     if (ctx->ev1) (void)hipEventDestroy(ctx->ev1);
+    if (ctx->ev_ppm) (void)hipEventDestroy(ctx->ev_ppm);
     delete ctx;
 }
 
@@ -240,6 +241,15 @@ int rt_set_camera(rt_context* ctx, const rt_camera_pod* cam)
     if (!cam) return fail(ctx, RT_ERR_INVALID, "rt_set_camera: null camera");
     ctx->cam = to_device(*cam);
     ctx->have_camera = true; ++ctx->camera_version;
+    return RT_OK;
+}
+
+int rt_set_camera_ray_lists(rt_context* ctx, int enabled)
+{
+    if (!ctx) return fail(nullptr, RT_ERR_INVALID, "rt_set_camera_ray_lists: null context");
+    // the tile classes come from the lists when there are lists and from probe rays otherwise: the kept work order is for one of the two
+    if (ctx->primary_lists != (enabled != 0)) ctx->tile_key_valid = false;
+    ctx->primary_lists = enabled != 0;
     return RT_OK;
 }
 
@@ -425,7 +435,10 @@ extern "C" int rt_render_multi(rt_context** ctx, int n, const rt_params* p, floa
     if (!ctx || n <= 0) return fail(nullptr, RT_ERR_INVALID, "rt_render_multi: no contexts");
     for (int k = 0; k < n; ++k) if (!ctx[k]) return fail(nullptr, RT_ERR_INVALID, "rt_render_multi: context %d is null", k);
     for (int k = 0; k < n; ++k) for (int j = 0; j < k; ++j) if (ctx[j] == ctx[k]) return fail(ctx[0], RT_ERR_INVALID, "rt_render_multi: context %d is listed twice", k);
-    if (!params_ok(p)) return fail(ctx[0], RT_ERR_INVALID, "rt_render_multi: invalid parameters");
+    if (!p) return fail(ctx[0], RT_ERR_INVALID, "rt_render_multi: invalid parameters");
+    rt_params whole = *p;                   // band_first / band_step are documented as ignored: whatever they hold is not judged
+    whole.band_first = 0; whole.band_step = n;
+    if (!params_ok(&whole)) return fail(ctx[0], RT_ERR_INVALID, "rt_render_multi: invalid parameters");
     for (int k = 0; k < n; ++k) if (!ctx[k]->n || !ctx[k]->have_camera) return fail(ctx[0], RT_ERR_STATE, "rt_render_multi: context %d has no scene or camera", k);
     std::vector<int> rc(n, RT_OK); std::vector<uint64_t> r(n, 0); std::vector<float> ms(n, 0.0f);
     std::vector<std::thread> workers;
@@ -434,9 +447,9 @@ extern "C" int rt_render_multi(rt_context** ctx, int n, const rt_params* p, floa
     bool started_all = true;
     try {
         workers.reserve((size_t)n);
-        for (int k = 1; k < n; ++k) workers.emplace_back([&, k] { rc[k] = render_share(ctx[k], k, n, *p, h_rgb_mean, h_irgb, &r[k], &ms[k]); });
+        for (int k = 1; k < n; ++k) workers.emplace_back([&, k] { rc[k] = render_share(ctx[k], k, n, whole, h_rgb_mean, h_irgb, &r[k], &ms[k]); });
     } catch (const std::exception&) { started_all = false; }
-    if (started_all) rc[0] = render_share(ctx[0], 0, n, *p, h_rgb_mean, h_irgb, &r[0], &ms[0]);
+    if (started_all) rc[0] = render_share(ctx[0], 0, n, whole, h_rgb_mean, h_irgb, &r[0], &ms[0]);
     for (std::thread& t : workers) t.join();
     if (!started_all) return fail(ctx[0], RT_ERR_STATE, "rt_render_multi: could not start %d host threads", n - 1);
     uint64_t total = 0;

@@ -48,7 +48,7 @@ struct rt_context {
     uint64_t last_samples = 0;                // primary rays of the last render (owned pixels x spp)
     float* d_out_rgb = nullptr; int32_t* d_out_irgb = nullptr; size_t out_rgb_bytes = 0, out_irgb_bytes = 0;   // device side of rt_render's host outputs (grow-only)
     void* d_ppm_scratch = nullptr; size_t ppm_scratch_bytes = 0;    // per-block lengths and offsets of the PPM encoder
-    hipStream_t ppm_stream = nullptr; bool ppm_pending = false;     // stream of the last rt_encode_ppm_device whose write pass may still run
+    hipEvent_t ev_ppm = nullptr; bool ppm_pending = false;          // recorded behind the write pass of the last rt_encode_ppm_device
     void* d_ppm_static = nullptr;                                  // this GPU's copy of the static scratch of rt_encode_ppm_device_noalloc (never freed)
     hipEvent_t ev0 = nullptr, ev1 = nullptr; hipStream_t last_stream = nullptr; bool pending = false;
 };

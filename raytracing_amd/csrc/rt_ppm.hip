@@ -240,10 +240,12 @@ int rt_encode_ppm_device(rt_context* ctx, const int32_t* d_irgb, int width, int 
     a.blocks = (a.pixels + kPpmPxPerBlock - 1) / kPpmPxPerBlock;
     a.header_len = snprintf(a.header, sizeof a.header, "P3\n%d %d\n255\n", width, height);
     const size_t off_bytes = ((size_t)a.blocks + 1) * sizeof(unsigned long long), need = off_bytes + (size_t)a.blocks * sizeof(uint32_t);
-    // the write pass of the call before may still be reading the context's block offsets on another stream
-    if (ctx->ppm_pending && st != ctx->ppm_stream) HIP_TRY(ctx, hipStreamSynchronize(ctx->ppm_stream));
-    ctx->ppm_pending = false;
+    // The write pass of the call before may still be reading the context's block offsets, possibly on another stream: this call's
+    // kernels wait for the event recorded behind it.  (No stream handle is kept: the caller may have destroyed that stream since.)
+    if (!ctx->ev_ppm) HIP_TRY(ctx, hipEventCreateWithFlags(&ctx->ev_ppm, hipEventDisableTiming));
+    if (ctx->ppm_pending) HIP_TRY(ctx, hipStreamWaitEvent(st, ctx->ev_ppm, 0));
     if (ctx->ppm_scratch_bytes < need) {
+        if (ctx->ppm_pending) HIP_TRY(ctx, hipEventSynchronize(ctx->ev_ppm));       // the old buffer is about to be freed
         (void)hipFree(ctx->d_ppm_scratch); ctx->d_ppm_scratch = nullptr; ctx->ppm_scratch_bytes = 0;
         HIP_TRY(ctx, hipMalloc(&ctx->d_ppm_scratch, need));
         ctx->ppm_scratch_bytes = need;
@@ -261,7 +263,8 @@ int rt_encode_ppm_device(rt_context* ctx, const int32_t* d_irgb, int width, int 
     if (!d_text || cap < *bytes) return fail(ctx, RT_ERR_TOO_LARGE, "rt_encode_ppm_device: the text needs %lld bytes, capacity is %lld", (long long)*bytes, (long long)cap);
     hipLaunchKernelGGL(k_ppm_write, dim3(a.blocks), dim3(kPpmBlock), 0, st, a);
     HIP_TRY(ctx, hipGetLastError());
-    ctx->ppm_pending = true; ctx->ppm_stream = st;
+    HIP_TRY(ctx, hipEventRecord(ctx->ev_ppm, st));
+    ctx->ppm_pending = true;
     return RT_OK;
 }
 

@@ -82,11 +82,14 @@ struct SecTimer {
 #define RT_CHUNK_ITEMS 512
 #endif
 static constexpr int kChunkItems = RT_CHUNK_ITEMS;
-static constexpr int kStagedFloats = 16;       // one staged ray: 64 bytes (origin, direction, pixel key, sample, sample-buffer slot, first sphere, padding)
+static constexpr int kStagedFloats = 12;       // one staged ray: 48 bytes (origin, direction, pixel key, sample, sample-buffer slot, first sphere, 8 bytes of padding), written whole (three 16-byte stores) so that no line goes back to HBM partly written
 static constexpr int kTraceBlock = 512;         // 8 waves share one LDS copy of the scene records
 // k_trace with the matrix-pipe filter keeps that filter's A operands in LDS too (8 KB more at 487 spheres): 12 waves share one copy,
 // two such blocks per CU are the same six waves per SIMD
-__host__ __device__ constexpr int trace_block(bool mfma) { return mfma ? 768 : kTraceBlock; }
+#ifndef RT_MFMA_BLOCK
+#define RT_MFMA_BLOCK 768
+#endif
+__host__ __device__ constexpr int trace_block(bool mfma) { return mfma ? RT_MFMA_BLOCK : kTraceBlock; }
 // A staged ray is read back by another lane of the wave that wrote it, and its slot is rewritten for every chunk: the loads are
 // device-scope ones (sc1), so that a line of the previous chunk still in this CU's L1 is not served.  Three loads off one address
 // and one wait for the lot.
@@ -134,6 +137,14 @@ __device__ __forceinline__ float exact_r2(const float4& g, const ExactLds& lds, 
     return g.w;
 }
 
+// s_setprio takes an immediate
+__device__ __forceinline__ void set_wave_priority(int p)
+{
+    if (p >= 3) __builtin_amdgcn_s_setprio(3);
+    else if (p == 2) __builtin_amdgcn_s_setprio(2);
+    else if (p == 1) __builtin_amdgcn_s_setprio(1);
+    else __builtin_amdgcn_s_setprio(0);
+}
 typedef float f16acc __attribute__((ext_vector_type(16)));
 typedef short bf16x4 __attribute__((ext_vector_type(4)));
 // a's lanes 32-63 <-> b's lanes 0-31
@@ -151,8 +162,12 @@ __device__ __forceinline__ uint32_t bf16_bits(float x)
 
 template <bool kLds, bool kPlane, bool kPacked, bool kMfma = false>
 __device__ __forceinline__ void closest_hit(const RayD& ray, float tmin, const SweepScene& sw, const ExactLds& lds,
-                                            uint32_t* mask_words, float& closest, int& hit, SecTimer& T, bool active = true)
+                                            uint32_t* mask_words, float& closest, int& hit, SecTimer& T, bool active = true, int prio_after = 0)
 {
+    // prio_after (wave-uniform, matrix-pipe form only): the filter loop is a long run of independent instructions that can fill any
+    // issue slot, the exact passes and the shading that follow are chains of dependent ones; the wave drops to issue priority 0 for
+    // the filter and returns to prio_after behind it, so that on a SIMD the waves in their latency-bound sections issue first and
+    // the filtering waves take what is left (config 3: 80.1 -> 76.9 ms).
     // kMfma: the plane filter's dot product runs on the matrix pipe (filter_mfma below).  The matrix instruction and the
     // half-wave swaps around it work on the whole wave, so in this form the function is entered by ALL 64 lanes of the wave;
     // a lane without a ray (active == false) is given a NaN normal, which fails every test, and leaves with hit = -1.
@@ -321,12 +336,18 @@ __device__ __forceinline__ void closest_hit(const RayD& ray, float tmin, const S
 #pragma unroll
         for (int v = 0; v < 16; ++v) zero[v] = 0.0f;
         const f16acc d1 = __builtin_amdgcn_mfma_f32_32x32x8bf16_1k(a, mb1, zero, 0, 0, 0);
+#ifndef RT_MFMA_SERIAL
         const f16acc d2 = __builtin_amdgcn_mfma_f32_32x32x8bf16_1k(a, mb2, zero, 0, 0, 0);
+#endif
         float acc1 = 128.0f, acc2 = 128.0f;
         // (the [0, 1] median is folded into the FMA's clamp modifier; written this way, not as inline assembly, the compiler
         // sees the read of a matrix result and keeps the wait states it needs)
 #pragma unroll
         for (int v = 0; v < 16; ++v) acc1 = fmaf(acc1, 2.0f, __builtin_amdgcn_fmed3f(fmaf(-d1[v], d1[v], threshold88), 0.0f, 1.0f));
+#ifdef RT_MFMA_SERIAL
+        __builtin_amdgcn_sched_barrier(0);
+        const f16acc d2 = __builtin_amdgcn_mfma_f32_32x32x8bf16_1k(a, mb2, zero, 0, 0, 0);
+#endif
 #pragma unroll
         for (int v = 0; v < 16; ++v) acc2 = fmaf(acc2, 2.0f, __builtin_amdgcn_fmed3f(fmaf(-d2[v], d2[v], threshold88), 0.0f, 1.0f));
         uint32_t m1 = __float_as_uint(acc1), m2 = __float_as_uint(acc2);
@@ -357,6 +378,7 @@ __device__ __forceinline__ void closest_hit(const RayD& ray, float tmin, const S
             const uint2* ap = (kLds ? lds.arec : sw.arec) + (size_t)(sbase >> 5) * 64 + (threadIdx.x & 63u);
             uint2 a_next = ap[0];
             uint32_t seen = 0u;
+            set_wave_priority(0);
             for (int w = 0; w < words_here; ++w) {
                 const uint2 a_now = a_next;
                 if (w + 1 < words_here) a_next = ap[(w + 1) * 64];
@@ -366,6 +388,7 @@ __device__ __forceinline__ void closest_hit(const RayD& ray, float tmin, const S
             }
             nz = seen << (32 - words_here);
             words = words_here; base = send;
+            set_wave_priority(prio_after);
         } else {
             if (normalised != 0u) {
                 for (int w = 0; w < full_words; ++w) {
@@ -428,7 +451,9 @@ __device__ __forceinline__ void closest_hit(const RayD& ray, float tmin, const S
                 const float4 g = kLds ? lds.geom[k] : sw.frec[k];
                 const float dk = !kLds ? g.w : kPacked ? g.w : lds.disck[k];
                 const float b = fmaf(g.x, hx, fmaf(g.y, hy, fmaf(g.z, hz, nod)));
-                const float ew = fmaf(g.x, p2x, fmaf(g.y, p2y, fmaf(g.z, p2z, noo)));
+                // 2 o.c - |o|^2' as (o.c) doubled: four roundings like the filter's chain over 2 o, without keeping 2 o in registers
+                // (the compiler recomputed 2 o per survivor rather than hold three more registers across this loop)
+                const float ew = fmaf(fmaf(g.x, ray.o.x, fmaf(g.y, ray.o.y, g.z * ray.o.z)), 2.0f, noo);
                 const float e = fmaf(b, b, ew);
                 if (!(e - dk < 0.0f)) keep |= bit;
                 if (cand == 0u) {

@@ -365,6 +365,9 @@ __global__ void __launch_bounds__(trace_block(kMfma)) RT_TRACE_WAVES(kBvh, kLds)
                 // area in HBM; handing an item to a lane later is then three loads.  (Generating on demand
                 // ran this code on every trip of the main loop for the third of the lanes that had finished.)
                 T.mark(0);
+#ifdef RT_STAGE_PRIO
+                set_wave_priority(RT_STAGE_PRIO);
+#endif
                 uint32_t kept = 0;
                 // the list of the tile the current row belongs to: lane q holds candidate q (index and exact record), fetched when the tile changes
                 uint32_t list_tile = 0xffffffffu, cnt = kNoTileList; int cand = 0; float4 crec = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
@@ -435,11 +438,11 @@ __global__ void __launch_bounds__(trace_block(kMfma)) RT_TRACE_WAVES(kBvh, kLds)
                     kept += (uint32_t)__popcll(km);
                     if (keep) {
                         float* rec = staged + (size_t)slot * kStagedFloats;
-                        v4f ra, rb; v2f rc;
+                        v4f ra, rb, rc;
                         ra.x = gr.o.x; ra.y = gr.o.y; ra.z = gr.o.z; ra.w = gr.d.x;
                         rb.x = gr.d.y; rb.y = gr.d.z; rb.z = __uint_as_float(gp); rb.w = __uint_as_float(gs);
-                        rc.x = __uint_as_float(gstore); rc.y = __int_as_float(first);
-                        *reinterpret_cast<v4f*>(rec) = ra; *reinterpret_cast<v4f*>(rec + 4) = rb; *reinterpret_cast<v2f*>(rec + 8) = rc;
+                        rc.x = __uint_as_float(gstore); rc.y = __int_as_float(first); rc.z = 0.0f; rc.w = 0.0f;
+                        *reinterpret_cast<v4f*>(rec) = ra; *reinterpret_cast<v4f*>(rec + 4) = rb; *reinterpret_cast<v4f*>(rec + 8) = rc;
                     }
                 }
                 pool_end = g + kept;        // what is handed out is the staged rows, not the items
@@ -478,13 +481,14 @@ __global__ void __launch_bounds__(trace_block(kMfma)) RT_TRACE_WAVES(kBvh, kLds)
         // six times its issue time: a 50-bounce path started late keeps the whole launch waiting.  Waves that
         // hold a deep path are therefore given issue priority over their neighbours (same total work, the long
         // chains just finish sooner).
-        {
-            const int deepest = __any(active && depth >= RT_PRIO_3) ? 3 : __any(active && depth >= RT_PRIO_2) ? 2 : __any(active && depth >= RT_PRIO_1) ? 1 : 0;
-            if (deepest == 3) __builtin_amdgcn_s_setprio(3);
-            else if (deepest == 2) __builtin_amdgcn_s_setprio(2);
-            else if (deepest == 1) __builtin_amdgcn_s_setprio(1);
-            else __builtin_amdgcn_s_setprio(0);
-        }
+        // With the matrix-pipe filter every wave spends its filter loop at priority 0 (closest_hit) and everything else one level
+        // up, deep paths further up still.
+#ifndef RT_PRIO_BASE
+#define RT_PRIO_BASE 1
+#endif
+        const int deepest = __any(active && depth >= RT_PRIO_3) ? 3 : __any(active && depth >= RT_PRIO_2) ? 2 : __any(active && depth >= RT_PRIO_1) ? 1 : 0;
+        const int prio_other = kMfma ? (deepest + RT_PRIO_BASE > 3 ? 3 : deepest + RT_PRIO_BASE) : deepest;
+        set_wave_priority(prio_other);
         float closest = FLT_MAX; int hit = -1;
         const unsigned long long live = __ballot(active);
 #ifdef RT_WAVE_TIMELINE
@@ -494,7 +498,7 @@ __global__ void __launch_bounds__(trace_block(kMfma)) RT_TRACE_WAVES(kBvh, kLds)
 #endif
         if (kBvh) { if (active) closest_hit_bvh<kLds>(ray, a.tmin, a.bvh, exact_lds, mask_words, closest, hit); }
         else if (__popcll(live) <= kFewPaths) closest_hit_few<kLds>(ray, a.tmin, sw, exact_lds, live, lane, closest, hit);
-        else if constexpr (kMfma) closest_hit<kLds, true, true, true>(ray, a.tmin, sw, exact_lds, mask_words, closest, hit, T, active);     // the whole wave enters
+        else if constexpr (kMfma) closest_hit<kLds, true, true, true>(ray, a.tmin, sw, exact_lds, mask_words, closest, hit, T, active, prio_other);     // the whole wave enters
         else if (active) closest_hit<kLds, kPlane, true>(ray, a.tmin, sw, exact_lds, mask_words, closest, hit, T);
         rays += (uint32_t)__popcll(live); misses += (uint32_t)__popcll(__ballot(active && hit < 0));
         if (active) {
@@ -606,6 +610,8 @@ extern "C" int rt_test_tile_lists(rt_context* ctx, const rt_params* p, uint32_t*
     if (*tiles > (1ll << 24)) return fail(ctx, RT_ERR_TOO_LARGE, "rt_test_tile_lists: %lld tiles", (long long)*tiles);
     if (!lists || capacity_words < *tiles * kTileListWords) return fail(ctx, RT_ERR_TOO_LARGE, "rt_test_tile_lists: %lld words needed", (long long)(*tiles * kTileListWords));
     HIP_TRY(ctx, hipSetDevice(ctx->device));
+    // a render still in flight on another stream reads the lists this call is about to rebuild (and may free)
+    if (ctx->pending) HIP_TRY(ctx, hipEventSynchronize(ctx->ev1));
     const int rc = build_tile_lists(ctx, p, (int)owned, nullptr);
     if (rc != RT_OK) return rc;
     HIP_TRY(ctx, hipStreamSynchronize(nullptr));

@@ -36,10 +36,12 @@ def row_index(height, band_rows, world, device=None):
     return src.to(device) if device is not None else src
 
 
-def gather_rows(local, height, band_rows, rank, world, group=None, src_index=None):
+def gather_rows(local, height, band_rows, rank, world, group=None, src_index=None, force_collective=False):
     """local: [max_owned_rows, width, C] tensor whose first owned_row_count rows are valid.
-    Returns the assembled [height, width, C] image on rank 0 and None elsewhere."""
-    if world == 1:
+    Returns the assembled [height, width, C] image on rank 0 and None elsewhere.  A single rank returns its rows as they
+    are unless force_collective asks for the gather to run anyway (a one-rank process group: the backend is loaded and the
+    collective executes, which is how a one-GPU box rehearses the RCCL path)."""
+    if world == 1 and not force_collective:
         return local[:height]
     pad = max_owned_rows(height, band_rows, world)
     assert local.shape[0] == pad, (local.shape, pad)
