@@ -136,15 +136,28 @@ int rt_render_counters(rt_context *ctx, rt_counters *out);
 int rt_render(rt_context *ctx, const rt_params *p, float *h_rgb_mean, int32_t *h_irgb,
               uint64_t *rays, float *kernel_ms);
 
-/* One image over several GPUs of the node: the band decomposition of performance.h:133-155 / main_modern.cpp:197-219 with
+/* A share of the image by TILES rather than rows: the tile decomposition of performance.h:133-155 (create_tiles) /
+ * main_modern.cpp:197-219 with 8x8-pixel tiles.  p describes the whole image (band_first 0, band_step 1).  The library orders
+ * the tiles of an image by how long their paths can get (tiles that show glass, then metal, then diffuse spheres, then sky);
+ * share (share_first, share_step) is every share_step-th tile of that order from position share_first on, so that the
+ * share_step shares of an image all hold the same mix of expensive and cheap tiles and every tile stays a compact 8x8 block.
+ * Outputs, device pointers, any may be NULL: d_irgb_tiles / d_rgb_mean_tiles hold rt_owned_tiles() x 64 x 3 values,
+ * tile-major, pixel l of a tile at row l / 8, column l % 8 of the tile, padding pixels of edge tiles zero; d_tile_ids holds
+ * the image tile (row-major over ceil(height / 8) x ceil(width / 8) tiles) of each tile of the share.  RT_MODE_MEGAKERNEL and
+ * RT_MODE_BVH only.  Same values as rt_render_device for every pixel.  rt_render_stats / rt_render_counters work as after
+ * rt_render_device. */
+int64_t rt_owned_tiles(const rt_params *p, int share_first, int share_step);
+int rt_render_tiles_device(rt_context *ctx, const rt_params *p, int share_first, int share_step, float *d_rgb_mean_tiles,
+                           int32_t *d_irgb_tiles, uint32_t *d_tile_ids, void *stream);
+
+/* One image over several GPUs of the node: the tile decomposition of performance.h:133-155 / main_modern.cpp:197-219 with
  * GPUs in place of pool threads.  ctx[0..n) are contexts (normally one per GPU; several on one GPU also work) that all hold
- * the same scene and camera.  p describes the whole image; its band_first / band_step are ignored: context k renders bands
- * k, k + n, k + 2n, ... of p->band_rows rows each (1-row bands spread cheap sky rows and expensive sphere rows evenly).  One
- * host thread per context runs the render and copies that context's rows straight into their places in the caller's
- * images (a strided device-to-host copy per context -- the image is wanted on the host for output.ppm, so a hop through
- * GPU 0 would only add a copy).  h_irgb / h_rgb_mean: whole image, height x width x 3, either may be NULL.  rays: sum over
- * the contexts; kernel_ms: n values, one per context (may be NULL).  The assembled image is the one a single context
- * renders, bit for bit, because every uniform is keyed on the pixel. */
+ * the same scene and camera.  p describes the whole image; its band fields are ignored: context k renders tile share (k, n)
+ * (rt_render_tiles_device).  One host thread per context runs the render, copies that context's tiles to the host and puts
+ * them into their places in the caller's images (the image is wanted on the host for output.ppm, so a hop through GPU 0 would
+ * only add a copy).  h_irgb / h_rgb_mean: whole image, height x width x 3, either may be NULL.  rays: sum over the contexts;
+ * kernel_ms: n values, one per context (may be NULL).  The assembled image is the one a single context renders, bit for
+ * bit, because every uniform is keyed on the pixel. */
 int rt_render_multi(rt_context **ctx, int n, const rt_params *p, float *h_rgb_mean, int32_t *h_irgb, uint64_t *rays,
                     float *kernel_ms);
 

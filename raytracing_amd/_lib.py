@@ -13,7 +13,7 @@ LAMBERTIAN, METAL, DIELECTRIC = 0, 1, 2
 
 # every symbol include/rt_amd.h declares
 EXPORTS = ["rt_device_count", "rt_create", "rt_destroy", "rt_last_error", "rt_upload_scene", "rt_set_camera", "rt_set_camera_ray_lists",
-           "rt_owned_rows", "rt_owned_pixels", "rt_render_device", "rt_render_stats", "rt_render_counters", "rt_render", "rt_render_multi",
+           "rt_owned_rows", "rt_owned_pixels", "rt_owned_tiles", "rt_render_tiles_device", "rt_render_device", "rt_render_stats", "rt_render_counters", "rt_render", "rt_render_multi",
            "rt_scene_grid", "rt_build_hierarchy", "rt_format_ppm", "rt_write_ppm", "rt_write_ppm_binary", "rt_encode_ppm_device", "rt_encode_ppm_device_noalloc", "rt_write_ppm_device", "rt_test_sphere_hit", "rt_test_scatter", "rt_test_get_ray",
            "rt_test_helpers", "rt_test_tile_lists", "rt_test_philox"]
 
@@ -92,6 +92,9 @@ def load_library():
     L.rt_owned_pixels.argtypes = [C.POINTER(Params)]
     L.rt_owned_pixels.restype = C.c_int64
     L.rt_render_device.argtypes = [vp, C.POINTER(Params), vp, vp, vp]
+    L.rt_owned_tiles.argtypes = [C.POINTER(Params), C.c_int, C.c_int]
+    L.rt_owned_tiles.restype = C.c_int64
+    L.rt_render_tiles_device.argtypes = [vp, C.POINTER(Params), C.c_int, C.c_int, vp, vp, vp, vp]
     L.rt_render_stats.argtypes = [vp, C.POINTER(C.c_uint64), C.POINTER(C.c_float)]
     L.rt_render_counters.argtypes = [vp, C.POINTER(Counters)]
     L.rt_render.argtypes = [vp, C.POINTER(Params), fp, ip, C.POINTER(C.c_uint64), C.POINTER(C.c_float)]
@@ -248,6 +251,14 @@ class Renderer:
         """Device-pointer form (integers: e.g. torch.Tensor.data_ptr(), torch stream .cuda_stream)."""
         self._check(self._L.rt_render_device(self._ctx, C.byref(p), C.c_void_p(d_rgb_mean or None),
                                              C.c_void_p(d_irgb or None), C.c_void_p(stream or None)))
+
+    def owned_tiles(self, p, share_first, share_step):
+        return int(self._L.rt_owned_tiles(C.byref(p), share_first, share_step))
+
+    def render_tiles_device(self, p, share_first, share_step, d_rgb_mean_tiles=0, d_irgb_tiles=0, d_tile_ids=0, stream=0):
+        """Tile share (share_first, share_step) of the image p describes, tile-major, with the image tile of each (device pointers)."""
+        self._check(self._L.rt_render_tiles_device(self._ctx, C.byref(p), share_first, share_step, C.c_void_p(d_rgb_mean_tiles or None),
+                                                   C.c_void_p(d_irgb_tiles or None), C.c_void_p(d_tile_ids or None), C.c_void_p(stream or None)))
 
     def stats(self):
         rays, ms = C.c_uint64(0), C.c_float(0)

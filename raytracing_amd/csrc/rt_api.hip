@@ -55,7 +55,7 @@ int rt_create(int device_ordinal, rt_context** out)
     { const char* f = getenv("RT_AMD_TILE_ORDER"); ctx->tile_ordering = !(f && strcmp(f, "image") == 0); }
     { const char* f = getenv("RT_AMD_PRIMARY"); ctx->primary_lists = !(f && strcmp(f, "sweep") == 0); }
     hipError_t e = hipSetDevice(device_ordinal);
-    if (e == hipSuccess) e = hipMalloc(&ctx->d_rays, 2 * sizeof(unsigned long long));
+    if (e == hipSuccess) e = hipMalloc(&ctx->d_rays, 3 * sizeof(unsigned long long));
     if (e == hipSuccess) e = hipMalloc(&ctx->d_work, sizeof(unsigned int));
     if (e == hipSuccess) { hipDeviceProp_t prop; e = hipGetDeviceProperties(&prop, device_ordinal); if (e == hipSuccess) ctx->num_cu = prop.multiProcessorCount; }
     if (e == hipSuccess) e = hipEventCreate(&ctx->ev0);
@@ -267,33 +267,50 @@ int64_t rt_owned_rows(const rt_params* p)
 
 int64_t rt_owned_pixels(const rt_params* p) { return rt_owned_rows(p) * (p ? p->width : 0); }
 
-int rt_render_device(rt_context* ctx, const rt_params* p, float* d_rgb_mean, int32_t* d_irgb, void* stream)
+}  // extern "C"
+namespace {
+// Tiles of the image described by p (8x8 pixels, edge tiles padded).
+int64_t image_tiles(const rt_params* p) { return (int64_t)((p->width + 7) / 8) * ((p->height + 7) / 8); }
+
+// rt_render_device and rt_render_tiles_device.  share_step = 1, share_first = 0, tile_output = false: the rows p selects, row-major.
+int render_impl(rt_context* ctx, const char* who, const rt_params* p, int share_first, int share_step, bool tile_output,
+                float* d_rgb_mean, int32_t* d_irgb, uint32_t* d_tile_ids, void* stream)
 {
-    if (!ctx) return fail(nullptr, RT_ERR_INVALID, "rt_render_device: null context");
-    if (!params_ok(p)) return fail(ctx, RT_ERR_INVALID, "rt_render_device: invalid parameters");
-    if (!ctx->n || !ctx->have_camera) return fail(ctx, RT_ERR_STATE, "rt_render_device: scene and camera must be set first");
+    if (!ctx) return fail(nullptr, RT_ERR_INVALID, "%s: null context", who);
+    if (!params_ok(p)) return fail(ctx, RT_ERR_INVALID, "%s: invalid parameters", who);
+    if (!ctx->n || !ctx->have_camera) return fail(ctx, RT_ERR_STATE, "%s: scene and camera must be set first", who);
+    if (tile_output) {
+        if (share_step <= 0 || share_first < 0 || share_first >= share_step) return fail(ctx, RT_ERR_INVALID, "%s: share %d of %d", who, share_first, share_step);
+        if (p->band_first != 0 || p->band_step != 1) return fail(ctx, RT_ERR_INVALID, "%s: a tile share is a share of the whole image (band_first 0, band_step 1)", who);
+        if (p->mode != RT_MODE_MEGAKERNEL && p->mode != RT_MODE_BVH) return fail(ctx, RT_ERR_INVALID, "%s: tile shares are rendered by the megakernel (RT_MODE_MEGAKERNEL, RT_MODE_BVH)", who);
+    }
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     hipStream_t st = static_cast<hipStream_t>(stream);
     const int owned = (int)rt_owned_rows(p);
     // The counters, the sample buffer, the staging rows, the hit stacks and the tile order belong to the context, not to the
     // call: a render enqueued on another stream than the one before has to start after that one has finished with them.
     if (ctx->pending && st != ctx->last_stream) HIP_TRY(ctx, hipStreamWaitEvent(st, ctx->ev1, 0));
-    HIP_TRY(ctx, hipMemsetAsync(ctx->d_rays, 0, 2 * sizeof(unsigned long long), st));
+    HIP_TRY(ctx, hipMemsetAsync(ctx->d_rays, 0, 3 * sizeof(unsigned long long), st));
     HIP_TRY(ctx, hipEventRecord(ctx->ev0, st));
-    if (owned > 0) {
+    const int64_t all_tiles = image_tiles(p);
+    const int64_t share_tiles = tile_output ? (all_tiles - share_first + share_step - 1) / share_step : 0;
+    if (owned > 0 && !(tile_output && share_tiles <= 0)) {
         RenderFrame f{};
         f.p = p; f.owned = owned; f.d_rgb_mean = d_rgb_mean; f.d_irgb = d_irgb; f.st = st;
+        f.share_first = 0; f.share_step = 1; f.tile_output = false; f.d_tile_ids = nullptr;
         if (p->mode == RT_MODE_PIXEL) {
             const int rc = pixel_render(ctx, f);
             if (rc != RT_OK) return rc;
         } else {
             f.tiles_x = (p->width + 7) / 8;
-            f.Q = (uint64_t)f.tiles_x * ((owned + 7) / 8) * 64;
+            f.image_tiles = (uint32_t)((uint64_t)f.tiles_x * ((owned + 7) / 8));
+            f.Q = (uint64_t)f.image_tiles * 64;
+            if (tile_output) { f.share_first = share_first; f.share_step = share_step; f.tile_output = true; f.d_tile_ids = d_tile_ids; f.Q = (uint64_t)share_tiles * 64; }
             // sample batches: the per-batch sample buffer stays below 16 GiB (of 288 GB of HBM) and item ids below 2^31;
             // every batch ends with the drain of its longest paths, so fewer, larger batches are better
             uint64_t per_batch = ctx->sample_buffer_cap / (f.Q * 12);
             if (per_batch > (1ull << 31) / f.Q) per_batch = (1ull << 31) / f.Q;
-            if (per_batch == 0) return fail(ctx, RT_ERR_TOO_LARGE, "rt_render_device: %llu pixels in one call exceed the sample-buffer limit; split the image into bands", (unsigned long long)f.Q);
+            if (per_batch == 0) return fail(ctx, RT_ERR_TOO_LARGE, "%s: %llu pixels in one call exceed the sample-buffer limit; split the image into bands", who, (unsigned long long)f.Q);
             f.batches = (int)((p->spp + per_batch - 1) / per_batch);
             f.s_per = (p->spp + f.batches - 1) / f.batches;
             const size_t need = (size_t)f.Q * f.s_per * 12;
@@ -320,7 +337,28 @@ int rt_render_device(rt_context* ctx, const rt_params* p, float* d_rgb_mean, int
     }
     HIP_TRY(ctx, hipEventRecord(ctx->ev1, st));
     ctx->last_stream = st; ctx->pending = true; ctx->last_samples = (uint64_t)rt_owned_pixels(p) * (uint64_t)p->spp;
+    ctx->last_was_share = tile_output; ctx->last_spp = p->spp;
     return RT_OK;
+}
+}  // namespace
+extern "C" {
+
+int rt_render_device(rt_context* ctx, const rt_params* p, float* d_rgb_mean, int32_t* d_irgb, void* stream)
+{
+    return render_impl(ctx, "rt_render_device", p, 0, 1, false, d_rgb_mean, d_irgb, nullptr, stream);
+}
+
+int64_t rt_owned_tiles(const rt_params* p, int share_first, int share_step)
+{
+    if (!params_ok(p) || share_step <= 0 || share_first < 0 || share_first >= share_step) return 0;
+    const int64_t all = image_tiles(p);
+    return all > share_first ? (all - share_first + share_step - 1) / share_step : 0;
+}
+
+int rt_render_tiles_device(rt_context* ctx, const rt_params* p, int share_first, int share_step, float* d_rgb_mean_tiles, int32_t* d_irgb_tiles,
+                           uint32_t* d_tile_ids, void* stream)
+{
+    return render_impl(ctx, "rt_render_tiles_device", p, share_first, share_step, true, d_rgb_mean_tiles, d_irgb_tiles, d_tile_ids, stream);
 }
 
 int rt_render_stats(rt_context* ctx, uint64_t* rays, float* kernel_ms)
@@ -351,7 +389,13 @@ int rt_render_counters(rt_context* ctx, rt_counters* out)
     out->rays_traced = c[0];
     out->intersection_tests = c[0] - c[1];
     // every Color() call beyond the first of a sample was made by a successful Scatter below the depth cap
-    out->material_evaluations = c[0] - ctx->last_samples;
+    uint64_t primary = ctx->last_samples;
+    if (ctx->last_was_share) {                 // a tile share: its pixels were counted on the device
+        unsigned long long px = 0;
+        HIP_TRY(ctx, hipMemcpy(&px, ctx->d_rays + 2, sizeof px, hipMemcpyDeviceToHost));
+        primary = (uint64_t)px * (uint64_t)ctx->last_spp;
+    }
+    out->material_evaluations = c[0] - primary;
     return RT_OK;
 }
 
@@ -389,39 +433,50 @@ int rt_render(rt_context* ctx, const rt_params* p, float* h_rgb_mean, int32_t* h
 
 }  // extern "C"
 namespace {
-// Renders context k's share of the image and copies its rows into the caller's whole-image arrays.
+// Renders context k's share of the image -- every n-th tile of the work order (most expensive tiles first), so that all contexts
+// get the same mix -- and puts its tiles into their places in the caller's whole-image arrays.
 int render_share(rt_context* ctx, int k, int n, const rt_params& whole, float* h_rgb_mean, int32_t* h_irgb, uint64_t* rays, float* ms)
 {
     rt_params p = whole;
-    p.band_first = k; p.band_step = n;
-    const int64_t rows = rt_owned_rows(&p);
+    p.band_first = 0; p.band_step = 1; p.band_rows = whole.height;
+    if (p.mode != RT_MODE_MEGAKERNEL && p.mode != RT_MODE_BVH) p.mode = RT_MODE_MEGAKERNEL;      // (the other organisations know no tile shares; same image)
+    const int64_t tiles = rt_owned_tiles(&p, k, n);
     *rays = 0; *ms = 0.0f;
-    if (rows == 0) return RT_OK;
+    if (tiles == 0) return RT_OK;
     HIP_TRY(ctx, hipSetDevice(ctx->device));
-    const size_t npx = (size_t)rows * p.width;
-    if (h_rgb_mean && ctx->out_rgb_bytes < npx * 12) {
+    const size_t npx = (size_t)tiles * 64;
+    // (the device side of the outputs is kept in the context like rt_render's; the tile ids follow the integers or the floats)
+    const size_t id_bytes = (size_t)tiles * sizeof(uint32_t);
+    if (h_rgb_mean && ctx->out_rgb_bytes < npx * 12 + id_bytes) {
         (void)hipFree(ctx->d_out_rgb); ctx->d_out_rgb = nullptr; ctx->out_rgb_bytes = 0;
-        HIP_TRY(ctx, hipMalloc(&ctx->d_out_rgb, npx * 12)); ctx->out_rgb_bytes = npx * 12;
+        HIP_TRY(ctx, hipMalloc(&ctx->d_out_rgb, npx * 12 + id_bytes)); ctx->out_rgb_bytes = npx * 12 + id_bytes;
     }
-    if (h_irgb && ctx->out_irgb_bytes < npx * 12) {
+    if (h_irgb && ctx->out_irgb_bytes < npx * 12 + id_bytes) {
         (void)hipFree(ctx->d_out_irgb); ctx->d_out_irgb = nullptr; ctx->out_irgb_bytes = 0;
-        HIP_TRY(ctx, hipMalloc(&ctx->d_out_irgb, npx * 12)); ctx->out_irgb_bytes = npx * 12;
+        HIP_TRY(ctx, hipMalloc(&ctx->d_out_irgb, npx * 12 + id_bytes)); ctx->out_irgb_bytes = npx * 12 + id_bytes;
     }
-    int rc = rt_render_device(ctx, &p, h_rgb_mean ? ctx->d_out_rgb : nullptr, h_irgb ? ctx->d_out_irgb : nullptr, nullptr);
+    if (!h_rgb_mean && !h_irgb) {
+        int rc = rt_render_tiles_device(ctx, &p, k, n, nullptr, nullptr, nullptr, nullptr);
+        if (rc == RT_OK) rc = rt_render_stats(ctx, rays, ms);
+        return rc;
+    }
+    uint32_t* d_ids = reinterpret_cast<uint32_t*>(h_irgb ? reinterpret_cast<char*>(ctx->d_out_irgb) + npx * 12 : reinterpret_cast<char*>(ctx->d_out_rgb) + npx * 12);
+    int rc = rt_render_tiles_device(ctx, &p, k, n, h_rgb_mean ? ctx->d_out_rgb : nullptr, h_irgb ? ctx->d_out_irgb : nullptr, d_ids, nullptr);
     if (rc == RT_OK) rc = rt_render_stats(ctx, rays, ms);
     if (rc != RT_OK) return rc;
-    // Packed rows of this context -> their places in the image.  Its full bands are band_rows * width * 12 bytes each, one
-    // every n bands of the image: one strided copy; a shorter last band (height not a multiple of band_rows) goes separately.
-    const size_t band_bytes = (size_t)p.band_rows * p.width * 12;
-    const int64_t nbands = ((int64_t)p.height + p.band_rows - 1) / p.band_rows;
-    int64_t full = 0; int64_t tail_rows = 0, tail_band = -1;
-    for (int64_t b = k; b < nbands; b += n) {
-        if ((b + 1) * p.band_rows <= p.height) ++full; else { tail_rows = p.height - b * p.band_rows; tail_band = b; }
-    }
+    std::vector<uint32_t> ids((size_t)tiles);
+    HIP_TRY(ctx, hipMemcpy(ids.data(), d_ids, id_bytes, hipMemcpyDeviceToHost));
+    const int tiles_x = (p.width + 7) / 8;
     auto scatter = [&](void* host, const void* dev) -> int {
-        char* h = static_cast<char*>(host) + (size_t)k * band_bytes;
-        if (full > 0) HIP_TRY(ctx, hipMemcpy2D(h, (size_t)n * band_bytes, dev, band_bytes, band_bytes, (size_t)full, hipMemcpyDeviceToHost));
-        if (tail_band >= 0) HIP_TRY(ctx, hipMemcpy(static_cast<char*>(host) + (size_t)tail_band * band_bytes, static_cast<const char*>(dev) + (size_t)full * band_bytes, (size_t)tail_rows * p.width * 12, hipMemcpyDeviceToHost));
+        std::vector<uint32_t> packed(npx * 3);           // 12 bytes per pixel, floats or integers alike
+        HIP_TRY(ctx, hipMemcpy(packed.data(), dev, npx * 12, hipMemcpyDeviceToHost));
+        uint32_t* img = static_cast<uint32_t*>(host);
+        for (int64_t t = 0; t < tiles; ++t) {
+            const int ty = (int)(ids[(size_t)t] / (uint32_t)tiles_x), tx = (int)(ids[(size_t)t] % (uint32_t)tiles_x);
+            const int w = p.width - tx * 8 < 8 ? p.width - tx * 8 : 8, h = p.height - ty * 8 < 8 ? p.height - ty * 8 : 8;
+            for (int r = 0; r < h; ++r)
+                memcpy(img + ((size_t)(ty * 8 + r) * p.width + (size_t)tx * 8) * 3, packed.data() + ((size_t)t * 64 + (size_t)r * 8) * 3, (size_t)w * 12);
+        }
         return RT_OK;
     };
     if (h_rgb_mean) { rc = scatter(h_rgb_mean, ctx->d_out_rgb); if (rc != RT_OK) return rc; }

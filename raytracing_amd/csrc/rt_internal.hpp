@@ -44,7 +44,9 @@ struct rt_context {
     // sphere hierarchy of RT_MODE_BVH (rt_bvh.hpp), rebuilt with every scene upload
     float4* d_bvh_nodes = nullptr; uint32_t* d_bvh_leaf = nullptr; uint32_t* d_bvh_big = nullptr; int bvh_n_big = 0, bvh_depth = 0, bvh_nodes = 0;
     bool have_camera = false; CameraD cam{};
-    unsigned long long* d_rays = nullptr;      // [0] closest-hit queries, [1] those that hit nothing
+    unsigned long long* d_rays = nullptr;      // [0] closest-hit queries, [1] those that hit nothing, [2] pixels of a tile share that lie inside the image
+    bool last_was_share = false;               // the last render was a tile share: its primary-ray count is d_rays[2] x spp
+    int last_spp = 0;
     uint64_t last_samples = 0;                // primary rays of the last render (owned pixels x spp)
     float* d_out_rgb = nullptr; int32_t* d_out_irgb = nullptr; size_t out_rgb_bytes = 0, out_irgb_bytes = 0;   // device side of rt_render's host outputs (grow-only)
     void* d_ppm_scratch = nullptr; size_t ppm_scratch_bytes = 0;    // per-block lengths and offsets of the PPM encoder
@@ -63,6 +65,9 @@ struct RenderFrame {
     const rt_params* p; int owned;
     int tiles_x; uint64_t Q; int batches, s_per;
     float* d_rgb_mean; int32_t* d_irgb; hipStream_t st;
+    // tile share (rt_render_tiles_device): the call renders every share_step-th tile of the work order from share_first on, Q
+    // counts its tiles only, and the outputs are tile-major with the image tile of each in d_tile_ids
+    uint32_t image_tiles; int share_first, share_step; bool tile_output; uint32_t* d_tile_ids;
 };
 struct SampleBatch { int index, s0, sc; };
 // What trace_prepare settles once per call for the batches of k_trace.

@@ -34,6 +34,7 @@ struct TraceArgs {
     uint32_t k0, k1;
     int band_rows, band_first, band_step, owned_rows;
     int tiles_x; uint32_t Q;              // padded pixel count = tiles * 64
+    int share_first, share_step, share_compact;          // tile share of the call (ItemGeometry)
     int s_begin, s_count;                 // sample batch
     uint32_t total_items;                 // Q * s_count  (< 2^31)
     int chunk_items;                      // items a wave reserves per atomic: a multiple of 64, at most kChunkItems
@@ -319,7 +320,7 @@ __global__ void __launch_bounds__(trace_block(kMfma)) RT_TRACE_WAVES(kBvh, kLds)
     const float fnx = (float)a.width, fny = (float)a.height;
     SecTimer T; T.start();
     ItemGeometry ig; ig.width = a.width; ig.height = a.height; ig.band_rows = a.band_rows; ig.band_first = a.band_first; ig.band_step = a.band_step;
-    ig.owned_rows = a.owned_rows; ig.tiles_x = a.tiles_x; ig.Q = a.Q; ig.s_begin = a.s_begin; ig.s_count = a.s_count; ig.tile_order = a.tile_order;
+    ig.owned_rows = a.owned_rows; ig.tiles_x = a.tiles_x; ig.Q = a.Q; ig.s_begin = a.s_begin; ig.s_count = a.s_count; ig.tile_order = a.tile_order; ig.share_first = a.share_first; ig.share_step = a.share_step; ig.share_compact = a.share_compact != 0;
     SweepScene sw; sw.arec = a.arec; sw.mfma_g = a.mfma_g; sw.frec = a.frec; sw.prec = a.prec; sw.force = a.force; sw.n_forced = a.n_forced; sw.plane_s0 = a.plane_s0; sw.plane_rmin = a.plane_rmin; sw.geom = a.geom; sw.n = a.n; sw.n_pad = a.n_pad;
 
 #ifdef RT_WAVE_TIMELINE
@@ -388,7 +389,7 @@ __global__ void __launch_bounds__(trace_block(kMfma)) RT_TRACE_WAVES(kBvh, kLds)
                         const uint32_t work_tile = ts / (uint32_t)a.s_count;
                         if (work_tile != list_tile) {
                             list_tile = work_tile;
-                            const uint32_t tile = a.tile_order ? a.tile_order[work_tile] : work_tile;
+                            const uint32_t tile = image_tile(ig, work_tile);
                             const uint32_t* list = a.tile_lists + (size_t)tile * kTileListWords;
                             cnt = (uint32_t)__builtin_amdgcn_readfirstlane((int)list[0]);
                             if (cnt != kNoTileList) {
@@ -551,6 +552,39 @@ __global__ void __launch_bounds__(256) k_resolve(const ResolveArgs a)
     if (a.rgb_mean) { a.rgb_mean[o] = mr; a.rgb_mean[o + 1] = mg; a.rgb_mean[o + 2] = mb; }
     if (a.irgb) { a.irgb[o] = quantise(mr); a.irgb[o + 1] = quantise(mg); a.irgb[o + 2] = quantise(mb); }
 }
+// The same ordered sum for a tile share: output tile-major, [work tile][pixel of the 8x8 tile][3], padding pixels of edge tiles
+// zero, and the image tile each work tile is (so that whoever assembles the image needs nothing but these two arrays).
+struct ResolveTilesArgs {
+    const float* samples; float* accum; uint32_t Q; int tiles_x; int s_count; int first, last;
+    int width, height, spp; int share_first, share_step; const uint32_t* tile_order;
+    float* rgb_mean; int32_t* irgb; uint32_t* tile_ids;
+    unsigned long long* pixel_counter;      // += the share's pixels inside the image (last batch only)
+};
+__global__ void __launch_bounds__(256) k_resolve_tiles(const ResolveTilesArgs a)
+{
+    const uint32_t q = blockIdx.x * 256u + threadIdx.x;
+    if (q >= a.Q) return;
+    const uint32_t wt = q >> 6, l = q & 63u;
+    const uint32_t pos = (uint32_t)a.share_first + wt * (uint32_t)a.share_step;
+    const uint32_t tile = a.tile_order ? a.tile_order[pos] : pos;
+    const int ty = (int)(tile / (uint32_t)a.tiles_x), tx = (int)(tile - (uint32_t)ty * (uint32_t)a.tiles_x);
+    const int i = tx * 8 + (int)(l & 7u), y = ty * 8 + (int)(l >> 3);
+    const bool inside = i < a.width && y < a.height;
+    V3 col = a.first || !inside ? mk(0.0f, 0.0f, 0.0f) : mk(a.accum[3 * (size_t)q], a.accum[3 * (size_t)q + 1], a.accum[3 * (size_t)q + 2]);
+    if (inside) {
+        const float* sp = a.samples + 3 * ((size_t)wt * a.s_count * 64 + l);
+        for (int s = 0; s < a.s_count; ++s, sp += 3 * 64) col = col + mk(sp[0], sp[1], sp[2]);
+    }
+    if (!a.last) { a.accum[3 * (size_t)q] = col.x; a.accum[3 * (size_t)q + 1] = col.y; a.accum[3 * (size_t)q + 2] = col.z; return; }
+    const float inv = 1.0f / (float)a.spp;
+    const float mr = col.x * inv, mg = col.y * inv, mb = col.z * inv;
+    const size_t o = (size_t)q * 3;
+    if (a.rgb_mean) { a.rgb_mean[o] = inside ? mr : 0.0f; a.rgb_mean[o + 1] = inside ? mg : 0.0f; a.rgb_mean[o + 2] = inside ? mb : 0.0f; }
+    if (a.irgb) { a.irgb[o] = inside ? quantise(mr) : 0; a.irgb[o + 1] = inside ? quantise(mg) : 0; a.irgb[o + 2] = inside ? quantise(mb) : 0; }
+    if (a.tile_ids && l == 0u) a.tile_ids[wt] = tile;
+    const unsigned long long m = __ballot(inside);
+    if ((threadIdx.x & 63u) == 0u && m != 0ull) atomicAdd(a.pixel_counter, (unsigned long long)__popcll(m));
+}
 #ifdef RT_SECTION_TIMERS
 extern "C" int rt_debug_section_ticks(unsigned long long* out8, int reset)   /* kSections (12) values */
 {
@@ -650,7 +684,7 @@ int trace_prepare(rt_context* ctx, const RenderFrame& f, TracePlan* plan)
         HIP_TRY(ctx, hipMalloc(&ctx->d_staging, (lanes / 64) * kStagedFloats * kChunkItems * sizeof(float)));
         ctx->stacks_lanes = lanes;
     }
-    const uint32_t n_tiles = (uint32_t)(f.Q / 64);
+    const uint32_t n_tiles = f.image_tiles;          // classes, order and lists cover the whole image also when the call renders a share of its tiles
     if (ctx->primary_lists) { const int rc = build_tile_lists(ctx, p, f.owned, st); if (rc != RT_OK) return rc; }
     t.ordered = ctx->tile_ordering;
     if (!t.ordered) return RT_OK;
@@ -666,7 +700,7 @@ int trace_prepare(rt_context* ctx, const RenderFrame& f, TracePlan* plan)
     TileArgs ta{};
     ta.geom = ctx->d_geom; ta.aux = ctx->d_aux; ta.n = ctx->n; ta.cam = ctx->cam; ta.tmin = p->tmin;
     ta.ig.width = p->width; ta.ig.height = p->height; ta.ig.band_rows = p->band_rows; ta.ig.band_first = p->band_first; ta.ig.band_step = p->band_step;
-    ta.ig.owned_rows = f.owned; ta.ig.tiles_x = f.tiles_x; ta.ig.Q = (uint32_t)f.Q; ta.ig.s_begin = 0; ta.ig.s_count = 1; ta.ig.tile_order = nullptr;
+    ta.ig.owned_rows = f.owned; ta.ig.tiles_x = f.tiles_x; ta.ig.Q = n_tiles * 64u; ta.ig.s_begin = 0; ta.ig.s_count = 1; ta.ig.tile_order = nullptr;
     ta.tiles = n_tiles; ta.cls = ctx->d_tile_cls; ta.order = ctx->d_tile_order;
     if (ctx->primary_lists) hipLaunchKernelGGL(k_tile_class_from_lists, dim3((n_tiles + 255u) / 256u), dim3(256), 0, st, ctx->d_tile_lists, ctx->d_aux, n_tiles, ctx->d_tile_cls);
     else hipLaunchKernelGGL(k_tile_class, dim3((n_tiles * 8u + 255u) / 256u), dim3(256), 0, st, ta);
@@ -684,7 +718,7 @@ int trace_batch(rt_context* ctx, const RenderFrame& f, const TracePlan& t, const
     a.width = p->width; a.height = p->height; a.max_depth = p->max_depth; a.tmin = p->tmin;
     a.k0 = (uint32_t)p->seed; a.k1 = (uint32_t)(p->seed >> 32);
     a.band_rows = p->band_rows; a.band_first = p->band_first; a.band_step = p->band_step; a.owned_rows = f.owned;
-    a.tiles_x = f.tiles_x; a.Q = (uint32_t)f.Q; a.s_begin = b.s0; a.s_count = b.sc; a.total_items = (uint32_t)(f.Q * b.sc);
+    a.tiles_x = f.tiles_x; a.Q = (uint32_t)f.Q; a.share_first = f.share_first; a.share_step = f.share_step; a.share_compact = f.tile_output ? 1 : 0; a.s_begin = b.s0; a.s_count = b.sc; a.total_items = (uint32_t)(f.Q * b.sc);
     a.samples = ctx->d_samples; a.ray_counter = ctx->d_rays; a.work_counter = ctx->d_work;
     a.stacks = ctx->d_stacks; a.stack_stride = (uint32_t)ctx->stacks_lanes; a.staging = ctx->d_staging;
     a.tile_order = t.ordered ? ctx->d_tile_order : nullptr;
@@ -713,6 +747,16 @@ int trace_batch(rt_context* ctx, const RenderFrame& f, const TracePlan& t, const
 
 int resolve_batch(rt_context* ctx, const RenderFrame& f, const SampleBatch& b)
 {
+    if (f.tile_output) {
+        ResolveTilesArgs r;
+        r.samples = ctx->d_samples; r.accum = ctx->d_accum; r.Q = (uint32_t)f.Q; r.tiles_x = f.tiles_x; r.s_count = b.sc;
+        r.first = (b.index == 0); r.last = (b.index == f.batches - 1); r.width = f.p->width; r.height = f.p->height; r.spp = f.p->spp;
+        r.share_first = f.share_first; r.share_step = f.share_step; r.tile_order = ctx->tile_ordering ? ctx->d_tile_order : nullptr;
+        r.rgb_mean = f.d_rgb_mean; r.irgb = f.d_irgb; r.tile_ids = f.d_tile_ids; r.pixel_counter = ctx->d_rays + 2;
+        hipLaunchKernelGGL(k_resolve_tiles, dim3((unsigned)((f.Q + 255) / 256)), dim3(256), 0, f.st, r);
+        HIP_TRY(ctx, hipGetLastError());
+        return RT_OK;
+    }
     ResolveArgs r;
     r.samples = ctx->d_samples; r.accum = ctx->d_accum; r.Q = (uint32_t)f.Q; r.tiles_x = f.tiles_x; r.s_count = b.sc;
     r.first = (b.index == 0); r.last = (b.index == f.batches - 1); r.width = f.p->width; r.owned_rows = f.owned; r.spp = f.p->spp;

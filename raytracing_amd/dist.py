@@ -1,8 +1,14 @@
-"""Row-band partition of one image over ranks and the single gather that reassembles it.
+"""Partition of one image over ranks and the single gather that reassembles it.
 
 Every (pixel, sample) is independent and the scene and camera are replicated, so the only
-exchange step of the path is the gather of finished rows to rank 0.  Bands are dealt round-robin
-(band b -> rank b mod world) so that cheap sky rows and expensive sphere rows spread evenly.
+exchange step of the path is the gather of finished pixels to rank 0.  Two partitions:
+
+* by tiles (default of bench.py for N > 1): the library orders the 8x8 tiles of the image by how long their
+  paths can get and rank r renders every world-th tile of that order from position r on
+  (rt_render_tiles_device), so every rank holds the same mix of expensive and cheap tiles and tiles
+  stay compact; rank 0 gathers the tile-major buffers and puts the tiles in place by index;
+* by interleaved row bands (band b -> rank b mod world), the partition rt_params itself describes.
+
 Works on CUDA tensors over RCCL (backend "nccl") and on CPU tensors over gloo.
 """
 import torch
@@ -66,3 +72,86 @@ def render_image(rt, width, height, spp, seed=0, band_rows=8, rank=0, world=1, d
         out = torch.zeros((pad, width, 3), dtype=torch.int32, device=device)
     rt.render_device(p, d_irgb=out.data_ptr(), stream=torch.cuda.current_stream().cuda_stream)
     return gather_rows(out, height, band_rows, rank, world, group=group, src_index=src_index), out
+
+
+# ---------------------------------------------------------------------------- tile partition
+def tile_grid(width, height):
+    """(tiles_x, tiles_y) of 8x8 tiles, edge tiles padded."""
+    return (width + 7) // 8, (height + 7) // 8
+
+
+def owned_tile_count(width, height, rank, world):
+    tx, ty = tile_grid(width, height)
+    n = tx * ty
+    return (n - rank + world - 1) // world if n > rank else 0
+
+
+def max_owned_tiles(width, height, world):
+    return owned_tile_count(width, height, 0, world)
+
+
+def assemble_tiles(tiles, ids, width, height):
+    """tiles: [n, 64, C] tile-major pixels (pixel l of a tile at row l // 8, column l % 8), ids: [n] image tile of each
+    (row-major over the tile grid); every tile of the image exactly once.  Returns the [height, width, C] image."""
+    tx, ty = tile_grid(width, height)
+    assert tiles.shape[0] == tx * ty and ids.shape[0] == tx * ty, (tiles.shape, ids.shape, tx * ty)
+    full = torch.empty_like(tiles)
+    full[ids.long()] = tiles
+    c = tiles.shape[-1]
+    return full.view(ty, tx, 8, 8, c).permute(0, 2, 1, 3, 4).reshape(ty * 8, tx * 8, c)[:height, :width]
+
+
+class TileGather:
+    """The gather of a tile partition.  Which image tile sits where in every rank's buffer depends on scene, camera and image size
+    only, so the ids travel once (`set_ids`, one gather of 4 bytes per tile) and every step after that is ONE gather of pixels."""
+
+    def __init__(self, width, height, rank, world, group=None, force_collective=False):
+        self.width, self.height, self.rank, self.world, self.group = width, height, rank, world, group
+        self.collective = world > 1 or force_collective
+        self.pad = max_owned_tiles(width, height, world)
+        self.counts = [owned_tile_count(width, height, r, world) for r in range(world)]
+        self.ids = None            # rank 0: [tiles] image tile of every gathered tile, rank-major
+        self.have_ids = False      # every rank: set_ids() has run (all ranks take part in its gather)
+
+    def _gather(self, local):
+        if not self.collective:
+            return [local]
+        if self.rank == 0:
+            parts = [torch.empty_like(local) for _ in range(self.world)]
+            dist.gather(local, parts, dst=0, group=self.group)
+            return parts
+        dist.gather(local, None, dst=0, group=self.group)
+        return None
+
+    def set_ids(self, local_ids):
+        """local_ids: [pad] int32, the first owned_tile_count entries valid."""
+        assert local_ids.shape[0] == self.pad, (local_ids.shape, self.pad)
+        parts = self._gather(local_ids)
+        self.have_ids = True
+        if self.rank == 0:
+            self.ids = torch.cat([p[:n] for p, n in zip(parts, self.counts)])
+
+    def gather(self, local_tiles):
+        """local_tiles: [pad, 64, C].  Returns the assembled image on rank 0, None elsewhere."""
+        assert local_tiles.shape[0] == self.pad, (local_tiles.shape, self.pad)
+        parts = self._gather(local_tiles)
+        if self.rank != 0:
+            return None
+        assert self.ids is not None, "set_ids() first"
+        return assemble_tiles(torch.cat([p[:n] for p, n in zip(parts, self.counts)]), self.ids, self.width, self.height)
+
+
+def render_image_tiles(rt, width, height, spp, seed=0, rank=0, world=1, device=None, gatherer=None, out=None, mode=0, force_collective=False):
+    """Render this rank's tile share with `rt` into a device tensor and gather.  Returns (image on rank 0 | None, gatherer, local tiles)."""
+    p = rt.params(width, height, spp, seed=seed, mode=mode)
+    if gatherer is None:
+        gatherer = TileGather(width, height, rank, world, force_collective=force_collective)
+    if out is None:
+        out = torch.zeros((gatherer.pad, 64, 3), dtype=torch.int32, device=device)
+    need_ids = not gatherer.have_ids
+    ids = torch.zeros(gatherer.pad, dtype=torch.int32, device=device) if need_ids else None
+    rt.render_tiles_device(p, rank, world, d_irgb_tiles=out.data_ptr(), d_tile_ids=ids.data_ptr() if need_ids else 0,
+                           stream=torch.cuda.current_stream().cuda_stream)
+    if need_ids:
+        gatherer.set_ids(ids)
+    return gatherer.gather(out), gatherer, out

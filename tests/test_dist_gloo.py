@@ -102,3 +102,72 @@ def test_bench_starts_its_own_ranks():
     env2 = dict(env, WORLD_SIZE="3", RANK="0")
     r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--dry-run"], capture_output=True, text=True, timeout=120, env=env2, cwd=root)
     assert r.returncode != 0 and "must agree" in (r.stderr + r.stdout)
+
+
+# ---------------------------------------------------------------------------- tile partition
+def _tile_share_of(img, order, rank, world):
+    """What rt_render_tiles_device hands rank `rank`: every world-th tile of `order` from position rank on, tile-major, padded."""
+    h, w = img.shape[0], img.shape[1]
+    tx, ty = rdist.tile_grid(w, h)
+    padded = np.zeros((ty * 8, tx * 8, 3), dtype=np.int32)
+    padded[:h, :w] = img
+    tiles = padded.reshape(ty, 8, tx, 8, 3).transpose(0, 2, 1, 3, 4).reshape(ty * tx, 64, 3)
+    mine = order[rank::world]
+    pad = rdist.max_owned_tiles(w, h, world)
+    out = np.zeros((pad, 64, 3), dtype=np.int32)
+    ids = np.zeros(pad, dtype=np.int32)
+    out[:len(mine)] = tiles[mine]
+    ids[:len(mine)] = mine
+    return torch.from_numpy(out), torch.from_numpy(ids)
+
+
+def _tile_worker(rank, world, port, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    scene = O.SceneArrays.from_table(O.three_sphere_table())
+    _, whole, _ = O.render(scene, O.three_camera(W, H), W, H, SPP, O.usrc_philox(SEED))
+    tx, ty = rdist.tile_grid(W, H)
+    order = np.random.default_rng(5).permutation(tx * ty)           # stands in for the library's class-sorted work order
+    g = rdist.TileGather(W, H, rank, world)
+    for step in range(2):                                            # the ids travel once, the pixels every step
+        tiles, ids = _tile_share_of(whole + step, order, rank, world)
+        if not g.have_ids:
+            g.set_ids(ids)
+        img = g.gather(tiles)
+        if rank == 0:
+            q.put(img.numpy())
+        else:
+            assert img is None
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_two_rank_tile_gather_reassembles_image():
+    world = 2
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_tile_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    got = [q.get(timeout=120), q.get(timeout=120)]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    scene = O.SceneArrays.from_table(O.three_sphere_table())
+    _, want, _ = O.render(scene, O.three_camera(W, H), W, H, SPP, O.usrc_philox(SEED))
+    assert np.array_equal(got[0], want) and np.array_equal(got[1], want + 1)
+
+
+def test_tile_layout_covers_every_tile_once():
+    for width, height, world in [(1200, 800, 1), (1200, 800, 8), (3840, 2160, 8), (40, 27, 2), (13, 5, 4), (8, 8, 3)]:
+        tx, ty = rdist.tile_grid(width, height)
+        counts = [rdist.owned_tile_count(width, height, r, world) for r in range(world)]
+        assert sum(counts) == tx * ty and max(counts) == rdist.max_owned_tiles(width, height, world) and max(counts) - min(counts) <= 1
+        order = np.random.default_rng(width).permutation(tx * ty)
+        img = np.arange(height * width * 3, dtype=np.int32).reshape(height, width, 3)
+        parts = [_tile_share_of(img, order, r, world) for r in range(world)]
+        tiles = torch.cat([t[:n] for (t, _), n in zip(parts, counts)])
+        ids = torch.cat([i[:n] for (_, i), n in zip(parts, counts)])
+        assert np.array_equal(rdist.assemble_tiles(tiles, ids, width, height).numpy(), img)

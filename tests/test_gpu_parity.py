@@ -878,6 +878,9 @@ def test_config4_full_render_equals_its_eight_way_partition(rt):
     assert total == rays_whole
     assert torch.equal(parts, whole)
     assert int(whole.min()) >= 0 and int(whole.max()) <= 255
+    # and as the eight TILE shares of the tile partition (every eighth 8x8 tile of the work order per rank)
+    img, total = _assemble_tile_shares(rt, rt.params(W, H, S, seed=seed), 8)
+    assert total == rays_whole and torch.equal(img, whole)
     print(f"config 4 on one GPU: {ms:.0f} ms, {rays_whole / ms / 1e3:.0f} Mrays/s, checksum {int(whole.to(torch.int64).sum())}")
 
 
@@ -1060,3 +1063,80 @@ def test_config3_lists_and_sweep_render_the_same_image(rt):
     assert imgs[0][1] == imgs[1][1] and imgs[0][2] == imgs[1][2]
     assert torch.equal(imgs[0][0], imgs[1][0])
     assert 2.4 < imgs[0][1] / (W * H * S) < 3.0
+
+
+def _assemble_tile_shares(rt, p, n):
+    """The image of p from its n tile shares (rt_render_tiles_device), assembled as rank 0 of the multi-GPU path does it."""
+    import torch
+    from raytracing_amd import dist as rdist
+    tiles, ids, total = [], [], 0
+    for k in range(n):
+        cnt = rt.owned_tiles(p, k, n)
+        assert cnt == rdist.owned_tile_count(p.width, p.height, k, n)
+        t = torch.zeros((max(cnt, 1), 64, 3), dtype=torch.int32, device="cuda")
+        i = torch.full((max(cnt, 1),), -1, dtype=torch.int32, device="cuda")
+        rt.render_tiles_device(p, k, n, d_irgb_tiles=t.data_ptr(), d_tile_ids=i.data_ptr())
+        r, _ = rt.stats()
+        total += r
+        tiles.append(t[:cnt]); ids.append(i[:cnt])
+    return rdist.assemble_tiles(torch.cat(tiles), torch.cat(ids), p.width, p.height), total
+
+
+def test_tile_shares_assemble_to_the_whole_image(rt):
+    """One image dealt out by tiles (the multi-GPU partition): every n-th 8x8 tile of the work order per share.  Shares rendered one
+    after the other on this GPU assemble to the single-call image with the same ray count, for widths and heights that are not
+    multiples of eight, more shares than some images have tiles, several sample batches, and the hierarchy walk; the share's
+    counters follow RenderStats (main_modern.cpp:23-61) with its own pixels as the primary rays."""
+    import torch
+    for (W, H, S, scene) in ((104, 60, 3, "final"), (37, 13, 5, "three"), (8, 8, 4, "three")):
+        if scene == "final":
+            rt.upload_scene(R.final_scene_table()); rt.set_camera(R.final_camera(W, H))
+        else:
+            rt.upload_scene(R.three_sphere_table()); rt.set_camera(R.three_camera(W, H))
+        for mode in (R.MODE_MEGAKERNEL, R.MODE_BVH):
+            p = rt.params(W, H, S, seed=31, mode=mode)
+            _, want, rays, _ = rt.render(p)
+            want_counters = rt.counters()
+            for n in (1, 2, 3, 8):
+                img, total = _assemble_tile_shares(rt, p, n)
+                assert total == rays, (W, H, mode, n)
+                assert np.array_equal(img.cpu().numpy(), want), (W, H, mode, n)
+            # counters of a lone share (n = 1) are those of the whole image
+            t = torch.zeros((rt.owned_tiles(p, 0, 1), 64, 3), dtype=torch.int32, device="cuda")
+            rt.render_tiles_device(p, 0, 1, d_irgb_tiles=t.data_ptr())
+            assert rt.counters() == want_counters
+    # float output and ids of a share; bad arguments
+    rt.upload_scene(R.final_scene_table()); rt.set_camera(R.final_camera(104, 60))
+    p = rt.params(104, 60, 3, seed=31)
+    rgb, _, _, _ = rt.render(p)
+    n = rt.owned_tiles(p, 1, 2)
+    f = torch.zeros((n, 64, 3), dtype=torch.float32, device="cuda"); ids = torch.zeros(n, dtype=torch.int32, device="cuda")
+    rt.render_tiles_device(p, 1, 2, d_rgb_mean_tiles=f.data_ptr(), d_tile_ids=ids.data_ptr())
+    rt.stats()
+    fh, ih = f.cpu().numpy(), ids.cpu().numpy()
+    for k in range(n):
+        ty, tx = divmod(int(ih[k]), 13)
+        block = np.zeros((8, 8, 3), np.float32)
+        part = rgb[ty * 8:ty * 8 + 8, tx * 8:tx * 8 + 8]
+        block[:part.shape[0], :part.shape[1]] = part
+        assert same(fh[k].reshape(8, 8, 3), block), k
+    for first, step in ((2, 2), (-1, 2), (0, 0)):
+        with pytest.raises(R.RtError):
+            rt.render_tiles_device(p, first, step)
+    with pytest.raises(R.RtError):
+        rt.render_tiles_device(rt.params(104, 60, 3, band_rows=8, band_first=1, band_step=2), 0, 2)
+    with pytest.raises(R.RtError):
+        rt.render_tiles_device(rt.params(104, 60, 3, mode=R.MODE_WAVEFRONT), 0, 2)
+
+
+def test_config3_eight_tile_shares_equal_the_whole_image(rt):
+    """Config 3 (1200x800, 500 samples per pixel) as its eight tile shares: same integer image, same ray count."""
+    import torch
+    W, H, S = 1200, 800, 500
+    rt.upload_scene(R.final_scene_table())
+    rt.set_camera(R.final_camera(W, H))
+    whole = torch.zeros((H, W, 3), dtype=torch.int32, device="cuda")
+    rt.render_device(rt.params(W, H, S, seed=0), 0, whole.data_ptr())
+    rays, _ = rt.stats()
+    img, total = _assemble_tile_shares(rt, rt.params(W, H, S, seed=0), 8)
+    assert total == rays and torch.equal(img, whole)

@@ -32,6 +32,7 @@ rays, ms = rt.stats()
 pad = rdist.max_owned_rows(H, 1, 1)
 gathered = rdist.gather_rows(local, H, 1, 0, 1, force_collective=True)      # dist.gather on the device tensor
 t = torch.tensor([float(rays), ms], dtype=torch.float64, device=dev)
+tiled, tg, _ = rdist.render_image_tiles(rt, W, H, S, seed=3, rank=0, world=1, device=dev, force_collective=True)      # the tile partition's two gathers
 tmax = t.clone(); dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
 tsum = t.clone(); dist.all_reduce(tsum, op=dist.ReduceOp.SUM)
 every = [torch.zeros_like(t)]
@@ -40,7 +41,7 @@ dist.barrier()
 torch.cuda.synchronize()
 _, want, want_rays, _ = rt.render(rt.params(W, H, S, seed=3))
 out = {"backend": dist.get_backend(), "world": dist.get_world_size(), "gathered_is_cuda": bool(gathered.is_cuda),
-       "gather_equals_local": bool(torch.equal(gathered, local[:H])), "image_equals_host_form": bool((gathered.cpu().numpy() == want).all()),
+       "gather_equals_local": bool(torch.equal(gathered, local[:H])), "image_equals_host_form": bool((gathered.cpu().numpy() == want).all()), "tile_image_equals_host_form": bool((tiled.cpu().numpy() == want).all()),
        "rays": int(rays), "rays_host_form": int(want_rays), "allreduce_ok": bool(torch.equal(tmax, t) and torch.equal(tsum, t) and torch.equal(every[0], t))}
 dist.destroy_process_group()
 print("RESULT " + json.dumps(out), flush=True)
@@ -64,7 +65,7 @@ def test_one_rank_nccl_group_gathers_device_rows():
     assert line, proc.stdout[-2000:]
     out = json.loads(line[-1][7:])
     assert out["backend"] == "nccl" and out["world"] == 1
-    assert out["gathered_is_cuda"] and out["gather_equals_local"] and out["image_equals_host_form"]
+    assert out["gathered_is_cuda"] and out["gather_equals_local"] and out["image_equals_host_form"] and out["tile_image_equals_host_form"]
     assert out["rays"] == out["rays_host_form"] and out["allreduce_ok"]
 
 

@@ -22,7 +22,14 @@ L = R.load_library()
 buf = np.zeros((8, 8192), dtype=np.uint64)
 for rep in range(2):
     band = next(b for b in (8, 4, 2, 1) if (800 // b) % ranks == 0)
-    rgb, irgb, rays, ms = rt.render(rt.params(1200, 800, spp, seed=0, max_depth=depth, band_rows=band, band_first=0, band_step=ranks))
+    if os.environ.get("RT_SHARE_TILES") == "1":          # rank 0's TILE share instead of its row bands
+        import torch
+        pt = rt.params(1200, 800, spp, seed=0, max_depth=depth)
+        tiles = torch.zeros((rt.owned_tiles(pt, 0, ranks), 64, 3), dtype=torch.int32, device="cuda")
+        rt.render_tiles_device(pt, 0, ranks, d_irgb_tiles=tiles.data_ptr())
+        rays, ms = rt.stats()
+    else:
+        rgb, irgb, rays, ms = rt.render(rt.params(1200, 800, spp, seed=0, max_depth=depth, band_rows=band, band_first=0, band_step=ranks))
 L.rt_debug_wave_times(buf.ctypes.data_as(C.POINTER(C.c_ulonglong)))
 live = buf[2] > 0
 t0 = buf[0][live].min()
