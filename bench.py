@@ -283,6 +283,9 @@ def roofline_block(args, n_spheres, rays_per_launch, kernel_ms, prof):
         block["valu_issue_frac"] = prof.get("valu_issue_frac")
         block["executed_is"] = ("FP32 operations the vector ALU executed per ray (profiled: FMA x 2 + ADD + MUL + transcendental wave-instructions x active lanes) x rays "
                                 "/ kernel time; valu_issue_frac = share of SIMD cycles in which a vector instruction was issued")
+        if prof.get("mfma_bf16_flop_per_ray"):
+            block["matrix_pipe"] = {"bf16_tflops": prof["mfma_bf16_flop_per_ray"] * rays_per_launch / (kernel_ms * 1e-3) / 1e12, "busy_frac": prof.get("mfma_busy_frac"),
+                                    "what": "the filter's dot products: bf16 operations the matrix pipe executed (profiled) x rays / kernel time; share of SIMD cycles the pipe was busy"}
         block["profile"] = prof["file"]
     return block
 

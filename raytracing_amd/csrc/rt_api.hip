@@ -13,6 +13,7 @@
 #include <vector>
 #include "rt_internal.hpp"
 #include "rt_bvh.hpp"
+static constexpr int kMaxLdsSpheresLimit = 1536;      // kMaxLdsSpheres of rt_sweep.hpp (this file does not include the kernels' header)
 
 static thread_local std::string g_error;
 
@@ -52,6 +53,7 @@ int rt_create(int device_ordinal, rt_context** out)
     // RT_AMD_TILE_ORDER=image works through the tiles in image order instead of longest-paths-first (A/B runs).
     // RT_AMD_SAMPLE_BUFFER_KB caps the sample buffer (tests use it to run the multi-batch path on small images).
     { const char* f = getenv("RT_AMD_SAMPLE_BUFFER_KB"); const long long kb = f ? atoll(f) : 0; if (kb > 0) ctx->sample_buffer_cap = (uint64_t)kb << 10; }
+    { const char* f = getenv("RT_AMD_MAX_LDS_SPHERES"); const int v = f ? atoi(f) : 0; if (v > 0 && v <= kMaxLdsSpheresLimit) ctx->max_lds_spheres = v; }
     { const char* f = getenv("RT_AMD_TILE_ORDER"); ctx->tile_ordering = !(f && strcmp(f, "image") == 0); }
     { const char* f = getenv("RT_AMD_PRIMARY"); ctx->primary_lists = !(f && strcmp(f, "sweep") == 0); }
     hipError_t e = hipSetDevice(device_ordinal);

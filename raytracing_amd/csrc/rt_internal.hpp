@@ -21,7 +21,7 @@ struct rt_context {
     std::string error;
     float4* d_geom = nullptr; float4* d_mat = nullptr; Aux* d_aux = nullptr; int n = 0;
     float4* d_frec = nullptr; float4* d_prec = nullptr; uint32_t* d_force = nullptr; int n_forced = 0; float plane_s0 = 0.0f; float plane_rmin = 1.0f; int n_pad = 0;
-    bool plane_filter = true;
+    bool plane_filter = true; int max_lds_spheres = 0;          // (RT_AMD_MAX_LDS_SPHERES: scenes above it keep their records out of LDS; measurements)
     uint2* d_arec = nullptr; float mfma_g = 0.0f; bool mfma_filter = true;     // matrix-pipe form of the plane filter (closest_hit in rt_sweep.hpp)
     float* d_samples = nullptr; size_t samples_bytes = 0;      // sample buffer of the persistent megakernel
     uint64_t sample_buffer_cap = 16ull << 30;                  // largest sample buffer per batch (bytes)

@@ -379,6 +379,9 @@ __device__ __forceinline__ void closest_hit(const RayD& ray, float tmin, const S
             uint2 a_next = ap[0];
             uint32_t seen = 0u;
             set_wave_priority(0);
+#ifdef RT_MFMA_UNROLL
+#pragma unroll RT_MFMA_UNROLL
+#endif
             for (int w = 0; w < words_here; ++w) {
                 const uint2 a_now = a_next;
                 if (w + 1 < words_here) a_next = ap[(w + 1) * 64];
@@ -448,7 +451,11 @@ __device__ __forceinline__ void closest_hit(const RayD& ray, float tmin, const S
                 const int k = cbase + jj;
                 // without the LDS mirror the discriminant-filter record itself is gathered: it holds the same centre as the exact
                 // record and the constant beside it (one 16-byte load per survivor instead of two)
+#ifdef RT_PASSA_ADDR
+                const float4 g = kLds ? *reinterpret_cast<const float4*>(reinterpret_cast<const char*>(lds.geom) + (((uint32_t)cbase << 4) + ((uint32_t)jj << 4))) : sw.frec[k];
+#else
                 const float4 g = kLds ? lds.geom[k] : sw.frec[k];
+#endif
                 const float dk = !kLds ? g.w : kPacked ? g.w : lds.disck[k];
                 const float b = fmaf(g.x, hx, fmaf(g.y, hy, fmaf(g.z, hz, nod)));
                 // 2 o.c - |o|^2' as (o.c) doubled: four roundings like the filter's chain over 2 o, without keeping 2 o in registers

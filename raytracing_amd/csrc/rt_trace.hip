@@ -307,7 +307,13 @@ __global__ void __launch_bounds__(trace_block(kMfma)) RT_TRACE_WAVES(kBvh, kLds)
     uint16_t* stack = a.stacks + (size_t)blockIdx.x * kTraceBlock + threadIdx.x;
     const size_t sstride = a.stack_stride;
 
-    KeyedUniforms U; U.k0 = a.k0; U.k1 = a.k1; U.slot(0, 0, 0); U.cur = U4{ 0, 0, 0, 0 };
+    // Philox products in the shading of the main loop: one 64-bit multiply per product (half the multiplier work) where the
+    // register allocation has room for the pairs -- with the matrix-pipe filter it has (config 3: 76.4 -> 74.9 ms); in the other
+    // variants the pairs cost the kernel spilled registers and more than they gain.
+#ifndef RT_MAIN_WIDE_PHILOX
+#define RT_MAIN_WIDE_PHILOX 1
+#endif
+    KeyedUniformsT<(kMfma && RT_MAIN_WIDE_PHILOX != 0)> U; U.k0 = a.k0; U.k1 = a.k1; U.slot(0, 0, 0); U.cur = U4{ 0, 0, 0, 0 };
     RayD ray; ray.o = mk(0, 0, 0); ray.d = mk(0, 0, 1);
     int depth = 0; uint32_t item = 0, pix = 0, smp = 0;
     bool active = false;
@@ -660,11 +666,19 @@ int trace_prepare(rt_context* ctx, const RenderFrame& f, TracePlan* plan)
     const rt_params* p = f.p;
     hipStream_t st = f.st;
     TracePlan& t = *plan;
-    t.lds = ctx->n <= kMaxLdsSpheres;
+    t.lds = ctx->n <= (ctx->max_lds_spheres > 0 ? ctx->max_lds_spheres : kMaxLdsSpheres);
     t.plane = ctx->plane_filter;
     t.bvh = p->mode == RT_MODE_BVH;
-    t.mfma = !t.bvh && t.plane && ctx->mfma_filter;
+    // (a matrix-pipe chunk costs the same for 1 sphere as for 32, about what the vector form spends on 20: tiny scenes stay on the
+    // vector ALU -- the four spheres of the three-sphere test scene: 1.40 against 1.58 ms at 400x225x100)
+    t.mfma = !t.bvh && t.plane && ctx->mfma_filter && ctx->n >= 20;
     t.block = trace_block(t.mfma);
+    // With the matrix-pipe filter a block keeps 40 + 16 bytes per sphere and 48 KB of mask words in LDS: two blocks per CU (six waves
+    // per SIMD) up to 585 spheres, one above.  One block per CU loses more than LDS-resident records gain (600 spheres: 4.98 ms with
+    // the records in LDS, 4.17 ms with them read from L2 at full occupancy; 1 536 spheres: 9.89 / 8.18 ms; tools/lds_threshold.py), so
+    // the records stay in LDS only while two blocks fit.
+    if (t.mfma && t.lds && ctx->max_lds_spheres == 0 &&
+        (size_t)ctx->n * kLdsBytesPerSphere + (size_t)((ctx->n + 31) / 32) * 512 + (size_t)(t.block / 64) * kSuperChunkWords * 64 * sizeof(uint32_t) > 80u * 1024u) t.lds = false;
     t.shmem = (t.lds ? (size_t)ctx->n * kLdsBytesPerSphere + (t.mfma ? (size_t)((ctx->n + 31) / 32) * 512 : 0) : 0) + (size_t)(t.block / 64) * (t.bvh ? kBvhStack : kSuperChunkWords) * 64 * sizeof(uint32_t);
     int& bpc = ctx->trace_blocks_per_cu[t.mfma ? (t.lds ? 7 : 6) : t.bvh ? (t.lds ? 5 : 4) : (t.lds ? 1 : 0) + (t.plane ? 2 : 0)];
     if (bpc == 0) {

@@ -15,7 +15,7 @@ import os
 import shutil
 import sys
 
-tag = sys.argv[1] if len(sys.argv) > 1 else "r02"
+tag = sys.argv[1] if len(sys.argv) > 1 else "r03"
 root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 src = os.path.join(root, "gpurun_out", tag)
 dst = os.path.join(root, "profiles")
@@ -44,9 +44,6 @@ for name in "abc":
 fetch, _ = counters("fetch")
 write, _ = counters("write")
 rfetch, _ = counters("fetch", "k_resolve")
-stats = glob.glob(os.path.join(src, "trace", "**", "*kernel_stats.csv"), recursive=True)
-if stats:
-    shutil.copy(stats[0], os.path.join(dst, f"{tag}_kernel_stats.csv"))
 shutil.copy(os.path.join(src, "bench.json"), os.path.join(dst, f"{tag}_bench_line.json"))
 
 kernel_cycles = c.get("GRBM_GUI_ACTIVE", 0.0) / 8.0                 # shader cycles the launch lasted
@@ -76,29 +73,22 @@ if kernel_cycles > 0:
     # the share of SIMD cycles with a vector instruction in the pipe)
     summary["valu_busy_gfx9_formula"] = c["SQ_ACTIVE_INST_VALU"] * 4 / SIMDS / kernel_cycles
     summary["valu_issue_frac"] = insts * 2 / SIMDS / kernel_cycles
-# kernel-trace of the default bench command: its k_trace launches are the headline workload's (config 3, ~90 ms each) and the
-# 23 short ones of the config-1 line; the statistics file averages over both, so the two groups are separated here
-# and, since the line carries a sweep_only object, the launches of that second context (camera rays swept like every other ray)
-groups = {"headline": [], "config1": [], "sweep_only": []}
-sweep_ms = (bench.get("sweep_only") or {}).get("kernel_ms_mean")
-head_ms = bench.get("kernel_ms_mean")
-for path in glob.glob(os.path.join(src, "trace", "**", "*kernel_trace.csv"), recursive=True):
-    for r in csv.DictReader(open(path)):
-        if "k_trace" in r["Kernel_Name"]:
-            ms = (float(r["End_Timestamp"]) - float(r["Start_Timestamp"])) * 1e-6
-            if ms <= 20.0:
-                groups["config1"].append(ms)
-            elif sweep_ms and abs(ms - sweep_ms) < abs(ms - head_ms):
-                groups["sweep_only"].append(ms)
-            else:
-                groups["headline"].append(ms)
-for g, v in groups.items():
-    if v:
-        summary[f"kernel_trace_{g}_launches"] = len(v)
-        summary[f"kernel_trace_{g}_mean_ms"] = sum(v) / len(v)
+# kernel-trace statistics, one command per launch group (tools/profile_round.sh): trace_c3 = the headline workload alone (config 3, brute
+# force), trace_c1 = the short launch, trace_lists = config 3 with the camera-ray shortcut, trace_c5 = the 20 000-sphere scene at 32 spp,
+# trace_default = the default command (headline + config-1 line + beyond_brute_force launches in one process)
+groups = {}
+for name in ("default", "c3", "c1", "lists", "c5"):
+    st = glob.glob(os.path.join(src, f"trace_{name}", "**", "*kernel_stats.csv"), recursive=True)
+    if not st:
+        continue
+    shutil.copy(st[0], os.path.join(dst, f"{tag}_kernel_stats_{name}.csv"))
+    for r in csv.DictReader(open(st[0])):
+        if "k_trace" in r["Name"]:
+            groups[name] = {"launches": int(r["Calls"]), "mean_ms": float(r["AverageNs"]) * 1e-6, "min_ms": float(r["MinNs"]) * 1e-6}
+summary["kernel_trace_groups"] = groups
+if "c3" in groups:
+    summary["kernel_trace_headline_mean_ms"] = groups["c3"]["mean_ms"]
 summary["bench_kernel_ms_mean"] = bench.get("kernel_ms_mean")
-with open(os.path.join(dst, f"{tag}_pmc_k_trace.json"), "w") as f:
-    json.dump(summary, f, indent=1)
 with open(os.path.join(dst, f"{tag}_pmc_k_trace.txt"), "w") as f:
     f.write(f"# k_trace, bench.py --spp 50 --steps 1 (one launch per pass, {rays:.4g} rays); passes a, b, c of tools/profile_round.sh\n")
     for k, v in sorted(c.items()):
@@ -116,9 +106,39 @@ with open(os.path.join(dst, f"{tag}_pmc_k_trace.txt"), "w") as f:
     f.write(f"# executed FP32 operations per ray: {executed_flop_per_ray_upper:.0f} with all 64 lanes counted, {executed_flop_per_ray_lanes:.0f} scaled by the active-lane share; "
             f"algorithmic (reference) work per ray: {18 * 487 + 150}\n")
     f.write(f"# HBM bytes per ray: {summary['hbm_bytes_per_ray']:.1f} (FETCH_SIZE x 2 + WRITE_SIZE)\n")
-    if groups["headline"]:
-        f.write(f"# rocprofv3 --kernel-trace of the default bench command: {len(groups['headline'])} k_trace launches of the headline workload, mean {summary['kernel_trace_headline_mean_ms']:.2f} ms "
-                f"(bench.py's HIP-event figure, which also spans k_resolve: {bench.get('kernel_ms_mean'):.2f} ms); {len(groups['config1'])} launches of the config-1 line, mean "
-                f"{summary.get('kernel_trace_config1_mean_ms', 0):.3f} ms; {len(groups['sweep_only'])} launches of the sweep_only comparison, mean {summary.get('kernel_trace_sweep_only_mean_ms', 0):.2f} ms "
-                f"-- the statistics file averages over the three groups\n")
+    for name, g in groups.items():
+        f.write(f"# rocprofv3 --kernel-trace, command group {name}: {g['launches']} k_trace launches, mean {g['mean_ms']:.3f} ms, min {g['min_ms']:.3f} ms ({tag}_kernel_stats_{name}.csv)\n")
+    f.write(f"# bench.py's HIP-event figure for the headline (spans k_trace and k_resolve): {bench.get('kernel_ms_mean'):.2f} ms\n")
+    dpass, _ = counters("d")
+    if dpass:
+        trips = rays / 64
+        f.write("# matrix pipe: " + ", ".join(f"{k} {v:.4g} ({v / trips:.1f} per 64 rays)" for k, v in sorted(dpass.items())) + "\n")
+        if "SQ_INSTS_VALU_MFMA_MOPS_BF16" in dpass:
+            # one count = 512 floating-point operations (a 32x32x8 instruction, 16 384 operations, counts 32)
+            summary["mfma_bf16_flop_per_ray"] = dpass["SQ_INSTS_VALU_MFMA_MOPS_BF16"] * 512.0 / rays
+            f.write(f"# bf16 operations on the matrix pipe per ray: {summary['mfma_bf16_flop_per_ray']:.0f} (SQ_INSTS_VALU_MFMA_MOPS_BF16 x 512)\n")
+        if kernel_cycles > 0 and "SQ_VALU_MFMA_BUSY_CYCLES" in dpass:
+            summary["mfma_busy_frac"] = dpass["SQ_VALU_MFMA_BUSY_CYCLES"] / SIMDS / kernel_cycles
+            f.write(f"# SQ_VALU_MFMA_BUSY_CYCLES / (SIMDs x kernel cycles) = {summary['mfma_busy_frac']:.3f}\n")
+# config 5: what the waves of the 20 000-sphere sweep wait for (filter operands and exact records from L2, nothing of the scene in LDS)
+c5 = {}
+for name in ("c5a", "c5b", "c5c"):
+    a5, _ = counters(name)
+    c5.update(a5)
+if c5:
+    with open(os.path.join(dst, f"{tag}_c5_pmc.txt"), "w") as f:
+        f.write("# k_trace on config 5's scene (20 000 spheres, 1920x1080, 8 spp, one launch per pass): passes c5a, c5b, c5c of tools/profile_round.sh\n")
+        for k, v in sorted(c5.items()):
+            f.write(f"{k} {v:.0f}\n")
+        wc5 = c5.get("SQ_WAVE_CYCLES", 0.0)
+        if wc5:
+            f.write(f"# wave time split: active {c5['SQ_ACTIVE_INST_ANY'] / wc5:.2f} issue-stall {c5['SQ_WAIT_INST_ANY'] / wc5:.2f} waitcnt {c5['SQ_WAIT_ANY'] / wc5:.2f}\n")
+        kc5 = c5.get("GRBM_GUI_ACTIVE", 0.0) / 8.0
+        if kc5:
+            f.write(f"# kernel {kc5:.4g} shader cycles; vector instructions x 2 cycles / SIMD cycles = {c5['SQ_INSTS_VALU'] * 2 / SIMDS / kc5:.3f}; "
+                    f"matrix pipe busy {c5.get('SQ_VALU_MFMA_BUSY_CYCLES', 0) / SIMDS / kc5:.3f}; LDS-issue stall share of wave time {c5.get('SQ_WAIT_INST_LDS', 0) / wc5:.4f}\n")
+        if c5.get("TCC_HIT_sum", 0) + c5.get("TCC_MISS_sum", 0) > 0:
+            f.write(f"# L2: hit rate {c5['TCC_HIT_sum'] / (c5['TCC_HIT_sum'] + c5['TCC_MISS_sum']):.4f}; L1 requests {c5.get('TCP_TOTAL_CACHE_ACCESSES_sum', 0):.4g}, of them to L2 {c5.get('TCP_TCC_READ_REQ_sum', 0):.4g}\n")
+with open(os.path.join(dst, f"{tag}_pmc_k_trace.json"), "w") as f:
+    json.dump(summary, f, indent=1)
 print(json.dumps(summary, indent=1))

@@ -28,7 +28,8 @@ def random_scene(rng, n):
 
 cases = int(sys.argv[1]) if len(sys.argv) > 1 else 200
 rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 1)
-rt = R.Renderer(0)
+rt = R.Renderer(0, camera_ray_lists=True)
+swept = R.Renderer(0, camera_ray_lists=False)          # camera rays through the brute-force sweep like every other ray
 W, H, S = 64, 40, 3
 t0 = time.time(); bad = 0
 for case in range(cases):
@@ -42,8 +43,9 @@ for case in range(cases):
     rt.upload_scene(table); rt.set_camera(cam)
     seed = 5000 + case
     lit = rt.render(rt.params(W, H, S, seed=seed, mode=R.MODE_PIXEL))
-    for mode, name in ((R.MODE_MEGAKERNEL, "megakernel"), (R.MODE_BVH, "bvh"), (R.MODE_WAVEFRONT, "wavefront")):
-        got = rt.render(rt.params(W, H, S, seed=seed, mode=mode))
+    swept.upload_scene(table); swept.set_camera(cam)
+    for mode, name in ((R.MODE_MEGAKERNEL, "megakernel"), (-1, "megakernel, camera rays swept"), (R.MODE_BVH, "bvh"), (R.MODE_WAVEFRONT, "wavefront")):
+        got = swept.render(swept.params(W, H, S, seed=seed, mode=R.MODE_MEGAKERNEL)) if mode < 0 else rt.render(rt.params(W, H, S, seed=seed, mode=mode))
         a, b = got[0].view(np.uint32), lit[0].view(np.uint32)
         same = ((got[0] == lit[0]) | (np.isnan(got[0]) & np.isnan(lit[0])))
         if got[2] != lit[2] or not same.all():

@@ -8,7 +8,9 @@
 //           verdict on the vector ALU (all operands vector registers); one v_permlane32_swap per chunk gives every lane the two
 //           16-bit halves of ITS ray's mask word, which goes to LDS like the shipped filter's;
 //   mode 2  as mode 1 with the A operand read from global memory (L1 / L2) instead of LDS, one chunk ahead;
-//   mode 3  v_mfma_f32_32x32x8_bf16_1k (K = 8, 8 bytes per lane for A), otherwise as mode 1.
+//   mode 3  v_mfma_f32_32x32x8_bf16_1k (K = 8, 8 bytes per lane for A), otherwise as mode 1;
+//   modes 4, 5  the MFMAs of mode 1 alone / the vector-ALU work of mode 1 alone; mode 6  mode 1 with the next half's MFMA issued early;
+//   mode 7  the form the render kernel ships: mode 3 with the accumulate chain started at 128 (no conversions) and v_perm_b32.
 // Reported: SIMD cycles per wave-pair (one sphere against the 64 rays of a wave) = time x clock x SIMDs / (waves x pairs).
 #include <hip/hip_runtime.h>
 #include <cstdio>
@@ -104,6 +106,32 @@ __global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(WAVES,
                     const uint32_t m = (m1 << 16) | m2;
                     words[c * 64] = m; nz |= m != 0u ? 0x80000000u >> c : 0u;
                 }
+            } else if (MODE == 7) {
+                // the shipped form: K = 8 instruction, chain started at 128 (verdict bits end up in the float's low half: no conversion),
+                // one v_perm_b32 to join the halves, survivor flag by add-with-carry
+                s4v b1, b2;
+                b1[0] = (short)L[0]; b1[1] = (short)(L[0] >> 16); b1[2] = (short)L[1]; b1[3] = (short)(L[1] >> 16);
+                b2[0] = (short)H[0]; b2[1] = (short)(H[0] >> 16); b2[2] = (short)H[1]; b2[3] = (short)(H[1] >> 16);
+                const uint2* lds_a2 = reinterpret_cast<const uint2*>(lds_a);
+                uint2 anext = lds_a2[lane];
+                uint32_t seen = 0;
+                for (int c = 0; c < chunks; ++c) {
+                    const uint2 araw = anext;
+                    anext = lds_a2[(c + 1) * 64 + lane];
+                    s4v a; a[0] = (short)araw.x; a[1] = (short)(araw.x >> 16); a[2] = (short)araw.y; a[3] = (short)(araw.y >> 16);
+                    const f16v d1 = __builtin_amdgcn_mfma_f32_32x32x8bf16_1k(a, b1, Z, 0, 0, 0);
+                    const f16v d2 = __builtin_amdgcn_mfma_f32_32x32x8bf16_1k(a, b2, Z, 0, 0, 0);
+                    float acc1 = 128.0f, acc2 = 128.0f;
+#pragma unroll
+                    for (int v = 0; v < 16; ++v) acc1 = fmaf(acc1, 2.0f, verdict_of(d1[v], T));
+#pragma unroll
+                    for (int v = 0; v < 16; ++v) acc2 = fmaf(acc2, 2.0f, verdict_of(d2[v], T));
+                    uint32_t m1 = __float_as_uint(acc1), m2 = __float_as_uint(acc2);
+                    swap32(m1, m2);
+                    const uint32_t m = __builtin_amdgcn_perm(m1, m2, 0x05040100u);
+                    words[c * 64] = m; seen = seen + seen + (m != 0u ? 1u : 0u);
+                }
+                nz = seen;
             } else if (MODE == 4) {
                 // the MFMAs alone, accumulating in place
                 bf16x8 b1, b2;
@@ -232,8 +260,8 @@ int main()
     printf("the vector-ALU work alone, 6 waves/SIMD      %8.3f ms  %6.2f\n", g, cyc(g, 6));
     const float h6 = run<6, 6>(recs, aimg, out, chunks, trips, e0, e1);
     printf("mfma 32x32x16, next half issued early, 6 w/S %8.3f ms  %6.2f\n", h6, cyc(h6, 6));
-    const float h5 = run<6, 5>(recs, aimg, out, chunks, trips, e0, e1);
-    printf("the same at 5 waves/SIMD (2 blocks of 640?)  %8.3f ms  %6.2f\n", h5, cyc(h5, 4));
+    const float s7 = run<7, 6>(recs, aimg, out, chunks, trips, e0, e1);
+    printf("shipped: 32x32x8 bf16_1k, no conversions     %8.3f ms  %6.2f\n", s7, cyc(s7, 6));
     CHECK(hipGetLastError());
     return 0;
 }
