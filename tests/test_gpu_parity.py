@@ -815,6 +815,21 @@ def test_sample_batches_accumulate_in_sample_order(monkeypatch, mode):
     rgb, irgb, rays, _ = r.render(r.params(m["nx"], m["ny"], m["ns"], seed=m["seed"], mode=mode))
     assert rays == m["rays"] and r.counters() == (m["rays"], m["hits"], m["scatters"])
     assert mismatch(rgb, want) == 0
+    if mode in (R.MODE_MEGAKERNEL, R.MODE_BVH):
+        # the same through tile shares, whose running sums are kept per work tile: three shares, several batches each
+        import torch
+        from raytracing_amd import dist as rdist
+        p = r.params(m["nx"], m["ny"], m["ns"], seed=m["seed"], mode=mode)
+        tiles, ids, total, counted = [], [], 0, [0, 0, 0]
+        for k in range(3):
+            cnt = r.owned_tiles(p, k, 3)
+            t = torch.zeros((cnt, 64, 3), dtype=torch.float32, device="cuda"); i = torch.zeros(cnt, dtype=torch.int32, device="cuda")
+            r.render_tiles_device(p, k, 3, d_rgb_mean_tiles=t.data_ptr(), d_tile_ids=i.data_ptr())
+            total += r.stats()[0]
+            counted = [a + b for a, b in zip(counted, r.counters())]
+            tiles.append(t); ids.append(i)
+        img = rdist.assemble_tiles(torch.cat(tiles), torch.cat(ids), m["nx"], m["ny"]).cpu().numpy()
+        assert total == m["rays"] and tuple(counted) == (m["rays"], m["hits"], m["scatters"]) and mismatch(img, want) == 0
     # a cap below one sample of the image is an error, not a crash
     monkeypatch.setenv("RT_AMD_SAMPLE_BUFFER_KB", "8")
     tiny = R.Renderer(0)

@@ -1,6 +1,6 @@
 // The plane filter of the render kernel in isolation, with the dot product of every (sphere, ray) pair on the bf16 matrix pipe,
 // at the render kernel's occupancy (512-thread blocks, 3 per CU = 6 waves per SIMD):
-//   mode 0  the scalar-operand form (two FMAs with an SGPR operand per pair, then verdict and accumulate): the round-2 filter;
+//   mode 0  the scalar-operand form (two FMAs with an SGPR operand per pair, then verdict and accumulate): the vector-ALU form (RT_AMD_FILTER=plane);
 //   mode 1  v_mfma_f32_32x32x16_bf16: q[sphere i][ray j] = sum over 16 bf16 terms (the f32 factors split into bf16 pieces), for
 //           32 spheres x 32 rays per instruction, two instructions per chunk of 32 spheres (rays 0-31, rays 32-63).  A operand
 //           (spheres) 16 bytes per lane per chunk from LDS, B operands (rays) built once per sweep with v_permlane32_swap.  Lane l
