@@ -279,6 +279,10 @@ template <bool kLds, bool kPlane, bool kBvh = false, bool kMfma = false>
 __global__ void __launch_bounds__(trace_block(kMfma)) RT_TRACE_WAVES(kBvh, kLds) k_trace(const TraceArgs a)
 {
     constexpr int kTraceBlock = trace_block(kMfma);       // (shadows the 512 of the other kernels inside this one)
+#ifndef RT_ITEM_IN_LDS
+#define RT_ITEM_IN_LDS 1
+#endif
+    constexpr bool kItemInLds = kMfma && RT_ITEM_IN_LDS != 0;
     extern __shared__ float4 smem[];
     // LDS: [geom n][mat n][aux n (8 B)] when kLds; geom in the packed form of ExactLds (centre, discriminant-filter constant)
     // for the sweep, in the plain form (centre, r*r) for the hierarchy walk.  With the matrix-pipe filter its A operands follow
@@ -299,6 +303,11 @@ __global__ void __launch_bounds__(trace_block(kMfma)) RT_TRACE_WAVES(kBvh, kLds)
     // (In RT_MODE_BVH the same area holds each lane's stack of pending nodes instead.)
     constexpr int kWordsPerLane = kBvh ? kBvhStack : kSuperChunkWords;
     uint32_t* mask_words = reinterpret_cast<uint32_t*>(lds_after_scene) + (size_t)wave * kWordsPerLane * 64 + lane;
+    // One more LDS word per lane behind the mask words (matrix-pipe variant: 3 KB per block, what is left under two blocks per CU):
+    // the sample-buffer slot of the lane's path, written when the lane takes an item and read once when its path ends.  In a
+    // register it was one of a dozen values the allocator kept in scratch memory, and every scratch store of the main loop went
+    // out to HBM (18 of 48 bytes written per ray).
+    uint32_t* item_slot = reinterpret_cast<uint32_t*>(lds_after_scene) + (size_t)(kTraceBlock / 64) * kWordsPerLane * 64 + threadIdx.x;
     __syncthreads();
     // The recursion's attenuation chain is replayed innermost-first when a path reaches the sky, so
     // each lane keeps the indices of the spheres it bounced off.  One 2-byte store per bounce and a
@@ -467,7 +476,7 @@ __global__ void __launch_bounds__(trace_block(kMfma)) RT_TRACE_WAVES(kBvh, kLds)
                 staged_read(staged + (size_t)slot * kStagedFloats, ra, rb, rc);
                 ray.o = mk(ra.x, ra.y, ra.z); ray.d = mk(ra.w, rb.x, rb.y);
                 pix = __float_as_uint(rb.z); smp = __float_as_uint(rb.w);
-                item = __float_as_uint(rc.x);               // where the sample is stored
+                if (kItemInLds) *item_slot = __float_as_uint(rc.x); else item = __float_as_uint(rc.x);               // where the sample is stored
                 // a staged second ray comes with the sphere its path left: the first entry of this lane's hit stack
                 const int first = __float_as_int(rc.y);
                 depth = 0;
@@ -514,7 +523,7 @@ __global__ void __launch_bounds__(trace_block(kMfma)) RT_TRACE_WAVES(kBvh, kLds)
             V3 sample;
             const bool done = shade_step<kLds>(ray, depth, closest, hit, pix, smp, a.max_depth, U, s_geom, s_mat, s_aux, a.geom, a.mat, a.aux, stack, sstride, sample, T);
             if (done) {
-                float* o = a.samples + (size_t)item * 3;
+                float* o = a.samples + (size_t)(kItemInLds ? *item_slot : item) * 3;
                 o[0] = sample.x; o[1] = sample.y; o[2] = sample.z;
                 active = false;
             }
@@ -678,8 +687,8 @@ int trace_prepare(rt_context* ctx, const RenderFrame& f, TracePlan* plan)
     // the records in LDS, 4.17 ms with them read from L2 at full occupancy; 1 536 spheres: 9.89 / 8.18 ms; tools/lds_threshold.py), so
     // the records stay in LDS only while two blocks fit.
     if (t.mfma && t.lds && ctx->max_lds_spheres == 0 &&
-        (size_t)ctx->n * kLdsBytesPerSphere + (size_t)((ctx->n + 31) / 32) * 512 + (size_t)(t.block / 64) * kSuperChunkWords * 64 * sizeof(uint32_t) > 80u * 1024u) t.lds = false;
-    t.shmem = (t.lds ? (size_t)ctx->n * kLdsBytesPerSphere + (t.mfma ? (size_t)((ctx->n + 31) / 32) * 512 : 0) : 0) + (size_t)(t.block / 64) * (t.bvh ? kBvhStack : kSuperChunkWords) * 64 * sizeof(uint32_t);
+        (size_t)ctx->n * kLdsBytesPerSphere + (size_t)((ctx->n + 31) / 32) * 512 + (size_t)(t.block / 64) * kSuperChunkWords * 64 * sizeof(uint32_t) + (size_t)t.block * sizeof(uint32_t) > 80u * 1024u) t.lds = false;
+    t.shmem = (t.lds ? (size_t)ctx->n * kLdsBytesPerSphere + (t.mfma ? (size_t)((ctx->n + 31) / 32) * 512 : 0) : 0) + (size_t)(t.block / 64) * (t.bvh ? kBvhStack : kSuperChunkWords) * 64 * sizeof(uint32_t) + (t.mfma ? (size_t)t.block * sizeof(uint32_t) : 0);
     int& bpc = ctx->trace_blocks_per_cu[t.mfma ? (t.lds ? 7 : 6) : t.bvh ? (t.lds ? 5 : 4) : (t.lds ? 1 : 0) + (t.plane ? 2 : 0)];
     if (bpc == 0) {
         int nb = 0;
