@@ -27,4 +27,7 @@ short="python bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-beyond --work
 pass c5a SQ_WAVES SQ_INSTS_VALU SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU
 pass c5b SQ_WAIT_INST_LDS SQ_INSTS_SMEM SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_VALU_MFMA_BUSY_CYCLES SQ_ACTIVE_INST_LDS GRBM_GUI_ACTIVE
 pass c5c TCP_TCC_READ_REQ_sum TCP_TOTAL_CACHE_ACCESSES_sum TCC_HIT_sum TCC_MISS_sum
+# the bench line that gets committed is taken AFTER the counters are summarised: bench.py reads the summary for its traffic and executed-work fields
+python tools/pmc_summary.py $tag > $out/summary.log 2>&1 || exit 1
+timeout -k 10 300 python bench.py > $out/bench.json 2> $out/bench.err || exit 1
 echo profile passes done
