@@ -54,6 +54,8 @@ int rt_create(int device_ordinal, rt_context** out)
     // RT_AMD_SAMPLE_BUFFER_KB caps the sample buffer (tests use it to run the multi-batch path on small images).
     { const char* f = getenv("RT_AMD_SAMPLE_BUFFER_KB"); const long long kb = f ? atoll(f) : 0; if (kb > 0) ctx->sample_buffer_cap = (uint64_t)kb << 10; }
     { const char* f = getenv("RT_AMD_MAX_LDS_SPHERES"); const int v = f ? atoi(f) : 0; if (v > 0 && v <= kMaxLdsSpheresLimit) ctx->max_lds_spheres = v; }
+    { const char* f = getenv("RT_AMD_CHUNK_ITEMS"); const int v = f ? atoi(f) : 0; if (v >= 64) ctx->chunk_cap = v / 64 * 64; }
+    { const char* f = getenv("RT_AMD_CHUNK_FACTOR"); const double v = f ? atof(f) : 0.0; if (v > 0.0) ctx->chunk_factor = (float)v; }
     { const char* f = getenv("RT_AMD_TILE_ORDER"); ctx->tile_ordering = !(f && strcmp(f, "image") == 0); }
     { const char* f = getenv("RT_AMD_PRIMARY"); ctx->primary_lists = !(f && strcmp(f, "sweep") == 0); }
     hipError_t e = hipSetDevice(device_ordinal);

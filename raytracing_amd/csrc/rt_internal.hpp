@@ -21,6 +21,7 @@ struct rt_context {
     std::string error;
     float4* d_geom = nullptr; float4* d_mat = nullptr; Aux* d_aux = nullptr; int n = 0;
     float4* d_frec = nullptr; float4* d_prec = nullptr; uint32_t* d_force = nullptr; int n_forced = 0; float plane_s0 = 0.0f; float plane_rmin = 1.0f; int n_pad = 0;
+    int chunk_cap = 0; float chunk_factor = 0.0f;                // (RT_AMD_CHUNK_ITEMS, RT_AMD_CHUNK_FACTOR: overrides of the work hand-out's chunk size; measurements)
     bool plane_filter = true; int max_lds_spheres = 0;          // (RT_AMD_MAX_LDS_SPHERES: scenes above it keep their records out of LDS; measurements)
     uint2* d_arec = nullptr; float mfma_g = 0.0f; bool mfma_filter = true;     // matrix-pipe form of the plane filter (closest_hit in rt_sweep.hpp)
     float* d_samples = nullptr; size_t samples_bytes = 0;      // sample buffer of the persistent megakernel

@@ -747,15 +747,18 @@ int trace_batch(rt_context* ctx, const RenderFrame& f, const TracePlan& t, const
     a.tile_order = t.ordered ? ctx->d_tile_order : nullptr;
     a.tile_lists = ctx->primary_lists ? ctx->d_tile_lists : nullptr;
     a.bvh.nodes = ctx->d_bvh_nodes; a.bvh.leaf_index = ctx->d_bvh_leaf; a.bvh.big = ctx->d_bvh_big; a.bvh.n_big = ctx->bvh_n_big; a.bvh.geom = ctx->d_geom;
-    // small jobs take smaller chunks so that every resident wave gets several (tail balance)
+    // Chunk size.  A chunk costs its wave a fixed amount (the atomic, and the wave's live paths standing still while it stages the
+    // chunk's camera rays), and what a wave still holds when the counter runs dry is proportional to the chunk: the sum is smallest
+    // for a chunk proportional to the square root of the items per resident wave.  Measured on the final scene at 1200x800 (ms per
+    // image at 31 / 62 / 125 / 250 / 500 samples): 2 sqrt(items per wave) 5.09 / 9.64 / 18.70 / 36.67 / 72.65, flat between factors
+    // 1.5 and 3; the earlier rule (items per wave / 16, at most 512) 5.6-5.8 / 10.2-10.8 / 19.1 / 37.0 / 72.7 -- an eighth of config 3,
+    // one rank's share on eight GPUs, is where the difference is largest.
     const uint64_t resident_waves = (uint64_t)ctx->num_cu * t.blocks_per_cu * (t.block / 64);
-#ifndef RT_CHUNK_DIV
-#define RT_CHUNK_DIV 16
-#endif
-    uint64_t chunk = (uint64_t)a.total_items / (resident_waves * RT_CHUNK_DIV) / 64 * 64;
+    uint64_t chunk = (uint64_t)((double)(ctx->chunk_factor > 0.0f ? ctx->chunk_factor : 2.0f) * sqrt((double)a.total_items / (double)resident_waves)) / 64 * 64;
     const uint64_t floor_items = (32768ull / (uint64_t)ctx->n_pad + 63) / 64 * 64;     // tiny scenes: keep per-chunk work above the hand-out overhead
     if (chunk < floor_items) chunk = floor_items;
-    a.chunk_items = (int)(chunk < 64 ? 64 : (chunk > (uint64_t)kChunkItems ? (uint64_t)kChunkItems : chunk));
+    const uint64_t chunk_cap = ctx->chunk_cap > 0 && ctx->chunk_cap < kChunkItems ? (uint64_t)ctx->chunk_cap : (uint64_t)kChunkItems;
+    a.chunk_items = (int)(chunk < 64 ? 64 : (chunk > chunk_cap ? chunk_cap : chunk));
     a.resident_waves = (uint32_t)resident_waves;
     { const uint64_t m = floor_items < 64 ? 64 : floor_items; a.min_chunk_items = (uint32_t)(m < (uint64_t)a.chunk_items ? m : (uint64_t)a.chunk_items); }
     const uint64_t want_blocks = ((uint64_t)a.total_items + (uint64_t)a.chunk_items * (t.block / 64) - 1) / ((uint64_t)a.chunk_items * (t.block / 64));

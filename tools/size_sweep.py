@@ -7,7 +7,8 @@ W, H = 1200, 800
 rt.set_camera(R.final_camera(W, H))
 out = torch.zeros((H, W, 3), dtype=torch.int32, device="cuda")
 prev = None
-for spp in (1, 2, 4, 8, 16, 31, 62, 125, 250, 500, 1000):
+import os, sys
+for spp in (tuple(int(v) for v in sys.argv[1:]) or (1, 2, 4, 8, 16, 31, 62, 125, 250, 500, 1000)):
     p = rt.params(W, H, spp, seed=0)
     best = 1e9
     for _ in range(4):
