@@ -738,15 +738,15 @@ __device__ __forceinline__ bool shade_step(RayD& ray, int& depth, float closest,
 // of edge tiles.
 //
 // tile_order (optional) is a permutation of the tiles: work position `tile` is image tile tile_order[tile], so
-// that the order in which tiles are WORKED on can differ from where their samples are STORED.  `store` is the
-// item number in image-tile order, i.e. the slot of the sample buffer.
+// that tiles can be WORKED on in another order than the image's.  The sample buffer is kept in work order -- `store`, the slot
+// of the item's sample, is the item number itself -- and the resolve kernels look a tile's work position up.
 //
 // A tile share (rt_render_tiles_device): the call works on every share_step-th position of the work order, starting at
-// share_first -- work tile w is position share_first + w * share_step -- and keeps its samples compactly, by work tile.  That is
+// share_first -- work tile w is position share_first + w * share_step.  That is
 // how one image is dealt out to several GPUs tile by tile: every share gets the same mix of expensive and cheap tiles.
 struct ItemGeometry {
     int width, height, band_rows, band_first, band_step, owned_rows, tiles_x; uint32_t Q; int s_begin, s_count; const uint32_t* tile_order;
-    int share_first = 0, share_step = 1; bool share_compact = false;      // share_compact: samples are kept by work tile (tile-major output)
+    int share_first = 0, share_step = 1;
 };
 __device__ __forceinline__ uint32_t image_tile(const ItemGeometry& ig, uint32_t work_tile)
 {
@@ -758,7 +758,7 @@ __device__ __forceinline__ bool decode_item(const ItemGeometry& ig, uint32_t ite
     const uint32_t ts = item >> 6, l = item & 63u;
     const uint32_t work_tile = ts / (uint32_t)ig.s_count, s_rel = ts - work_tile * (uint32_t)ig.s_count;
     const uint32_t tile = image_tile(ig, work_tile);
-    store = (((ig.share_compact ? work_tile : tile) * (uint32_t)ig.s_count + s_rel) << 6) + l;
+    store = item;
     const int ty = (int)(tile / (uint32_t)ig.tiles_x), tx = (int)(tile - (uint32_t)ty * (uint32_t)ig.tiles_x);
     i = tx * 8 + (int)(l & 7u);
     const int r = ty * 8 + (int)(l >> 3);

@@ -34,7 +34,7 @@ struct TraceArgs {
     uint32_t k0, k1;
     int band_rows, band_first, band_step, owned_rows;
     int tiles_x; uint32_t Q;              // padded pixel count = tiles * 64
-    int share_first, share_step, share_compact;          // tile share of the call (ItemGeometry)
+    int share_first, share_step;          // tile share of the call (ItemGeometry)
     int s_begin, s_count;                 // sample batch
     uint32_t total_items;                 // Q * s_count  (< 2^31)
     int chunk_items;                      // items a wave reserves per atomic: a multiple of 64, at most kChunkItems
@@ -48,6 +48,7 @@ struct TraceArgs {
     BvhScene bvh;                         // RT_MODE_BVH only
     uint16_t* stacks; uint32_t stack_stride;   // hit-index stacks in HBM: entry k of lane g at stacks[k * stack_stride + g]
     const uint32_t* tile_lists;           // per image tile: the spheres its camera rays can meet (k_tile_lists); null: every camera ray is swept
+    float* queue;                         // the camera ray of every item of the batch, row i = item i (k_primary); k_trace<..., kQueue = true> reads it
 };
 
 // ============================================================================ work order of the tiles
@@ -61,7 +62,7 @@ struct TraceArgs {
 struct TileArgs {
     const float4* geom; const Aux* aux; int n;
     CameraD cam; ItemGeometry ig; float tmin;
-    uint32_t tiles; uint32_t* cls; uint32_t* order;
+    uint32_t tiles; uint32_t* cls; uint32_t* order; uint32_t* rank;      // order[position] = image tile, rank[image tile] = position
 };
 
 // Eight probe rays per tile (corners and edge midpoints of the tile's pixel rectangle, through the lens
@@ -138,7 +139,7 @@ __global__ void __launch_bounds__(1024) k_tile_order(const TileArgs a)
         if (c < (uint32_t)kTileClasses) {
             uint32_t before = s_run[c];
             for (int w = 0; w < wave; ++w) before += s_wave[w][c];
-            a.order[before + rank] = i;
+            a.order[before + rank] = i; a.rank[i] = before + rank;
         }
         __syncthreads();
         if (threadIdx.x < kTileClasses) { uint32_t tot = 0; for (int w = 0; w < 16; ++w) tot += s_wave[w][threadIdx.x]; s_run[threadIdx.x] += tot; }
@@ -259,6 +260,34 @@ __global__ void __launch_bounds__(256) k_tile_class_from_lists(const uint32_t* l
     cls[tile] = c;
 }
 
+// ============================================================================ camera rays of a batch
+// When every camera ray is swept like any other ray (no per-tile lists), nothing about it depends on the scene: the camera rays of
+// a whole sample batch are generated by this kernel, one lane per item at full occupancy, and written to a queue in HBM in the order
+// of the items -- row i = item i: origin, direction, pixel key, sample number, 32 bytes -- and k_trace only reserves chunks of that
+// queue.  Generating them inside the persistent kernel (per chunk, into a staging area of the wave) kept two hundred instructions of
+// Philox and camera arithmetic, their registers and their scalar constants in a kernel that is held to 80 registers, and stopped a
+// wave's live paths while it staged: config 3 takes 72.6 ms that way (k_trace with 14 spilled registers), 66.0 + 3.9 ms this way
+// (k_trace without a spill).  The queue is written and read once (32 + 32 bytes per camera ray); the loop it feeds is
+// main.cpp:118-133, the ray is Camera::GetRay (camera.cpp:46-53).
+constexpr int kQueueFloats = 8;
+constexpr uint32_t kNoSample = 0xffffffffu;        // sample word of a row that holds no ray (padding pixel of an edge tile)
+__global__ void __launch_bounds__(256) k_primary(const TraceArgs a)
+{
+    const uint32_t it = blockIdx.x * 256u + threadIdx.x;
+    if (it >= a.total_items) return;
+    ItemGeometry ig; ig.width = a.width; ig.height = a.height; ig.band_rows = a.band_rows; ig.band_first = a.band_first; ig.band_step = a.band_step;
+    ig.owned_rows = a.owned_rows; ig.tiles_x = a.tiles_x; ig.Q = a.Q; ig.s_begin = a.s_begin; ig.s_count = a.s_count; ig.tile_order = a.tile_order; ig.share_first = a.share_first; ig.share_step = a.share_step;
+    uint32_t gp = 0u, gs = kNoSample, store = 0u; int i = 0, j = 0;
+    RayD gr; gr.o = mk(0, 0, 0); gr.d = mk(0, 0, 0);
+    if (decode_item(ig, it, gp, gs, i, j, store)) gr = camera_ray<true>(a.cam, gp, gs, i, j, (float)a.width, (float)a.height, a.k0, a.k1);
+    else gs = kNoSample;
+    v4f ra, rb;
+    ra.x = gr.o.x; ra.y = gr.o.y; ra.z = gr.o.z; ra.w = gr.d.x;
+    rb.x = gr.d.y; rb.y = gr.d.z; rb.z = __uint_as_float(gp); rb.w = __uint_as_float(gs);
+    v4f* row = reinterpret_cast<v4f*>(a.queue + (size_t)it * kQueueFloats);
+    row[0] = ra; row[1] = rb;
+}
+
 // Six waves per SIMD (three 512-thread blocks per CU) is what the LDS budget allows and what hides the latency of the exact
 // passes; the register allocation is held to it explicitly (80 VGPRs; the allocator's own choice drifts between 77 and 96
 // with small source changes).  The hierarchy walk with the scene in LDS fits two blocks per CU only, so it keeps more registers.
@@ -275,7 +304,7 @@ __global__ void __launch_bounds__(256) k_tile_class_from_lists(const uint32_t* l
 #endif
 constexpr bool kWidePhilox = RT_WIDE_PHILOX != 0;     // the staging phase of k_trace has the registers for 64-bit products
 constexpr int kUnresolved = -2;             // staging row 9: the staged ray is the camera ray itself (no list for its tile), not the path's second ray
-template <bool kLds, bool kPlane, bool kBvh = false, bool kMfma = false>
+template <bool kLds, bool kPlane, bool kBvh = false, bool kMfma = false, bool kQueue = false>
 __global__ void __launch_bounds__(trace_block(kMfma)) RT_TRACE_WAVES(kBvh, kLds) k_trace(const TraceArgs a)
 {
     constexpr int kTraceBlock = trace_block(kMfma);       // (shadows the 512 of the other kernels inside this one)
@@ -335,7 +364,7 @@ __global__ void __launch_bounds__(trace_block(kMfma)) RT_TRACE_WAVES(kBvh, kLds)
     const float fnx = (float)a.width, fny = (float)a.height;
     SecTimer T; T.start();
     ItemGeometry ig; ig.width = a.width; ig.height = a.height; ig.band_rows = a.band_rows; ig.band_first = a.band_first; ig.band_step = a.band_step;
-    ig.owned_rows = a.owned_rows; ig.tiles_x = a.tiles_x; ig.Q = a.Q; ig.s_begin = a.s_begin; ig.s_count = a.s_count; ig.tile_order = a.tile_order; ig.share_first = a.share_first; ig.share_step = a.share_step; ig.share_compact = a.share_compact != 0;
+    ig.owned_rows = a.owned_rows; ig.tiles_x = a.tiles_x; ig.Q = a.Q; ig.s_begin = a.s_begin; ig.s_count = a.s_count; ig.tile_order = a.tile_order; ig.share_first = a.share_first; ig.share_step = a.share_step;
     SweepScene sw; sw.arec = a.arec; sw.mfma_g = a.mfma_g; sw.frec = a.frec; sw.prec = a.prec; sw.force = a.force; sw.n_forced = a.n_forced; sw.plane_s0 = a.plane_s0; sw.plane_rmin = a.plane_rmin; sw.geom = a.geom; sw.n = a.n; sw.n_pad = a.n_pad;
 
 #ifdef RT_WAVE_TIMELINE
@@ -377,6 +406,9 @@ __global__ void __launch_bounds__(trace_block(kMfma)) RT_TRACE_WAVES(kBvh, kLds)
                 if (g >= a.total_items) { exhausted = true; break; }
                 pool_next = g; pool_base = g;
                 claim_end = (a.total_items - g < take) ? a.total_items : g + take;
+                if constexpr (kQueue) {
+                    pool_end = claim_end;          // the rows of the queue are the items themselves
+                } else {
                 // Generate the camera rays of the whole chunk now, all lanes busy, into this wave's staging
                 // area in HBM; handing an item to a lane later is then three loads.  (Generating on demand
                 // ran this code on every trip of the main loop for the third of the lanes that had finished.)
@@ -466,10 +498,26 @@ __global__ void __launch_bounds__(trace_block(kMfma)) RT_TRACE_WAVES(kBvh, kLds)
                 // the rows are read back by other lanes of this wave: drain the stores first
                 __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                }
             }
             const uint32_t avail = pool_end - pool_next;
             const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(need >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)need, 0u));
             const uint32_t want = (uint32_t)__popcll(need);
+            if constexpr (kQueue) {
+                if (!active && rank < avail) {
+                    const uint32_t row = pool_next + rank;
+                    const v4f* rec = reinterpret_cast<const v4f*>(a.queue + (size_t)row * kQueueFloats);
+                    const v4f ra = rec[0], rb = rec[1];
+                    smp = __float_as_uint(rb.w);
+                    if (smp != kNoSample) {
+                        ray.o = mk(ra.x, ra.y, ra.z); ray.d = mk(ra.w, rb.x, rb.y);
+                        pix = __float_as_uint(rb.z);
+                        if (kItemInLds) *item_slot = row; else item = row;          // the sample's slot is the item number
+                        depth = 0;
+                        active = true;
+                    }
+                }
+            } else
             if (!active && rank < avail) {
                 const uint32_t slot = pool_next + rank - pool_base;
                 v4f ra, rb; v2f rc;
@@ -485,7 +533,8 @@ __global__ void __launch_bounds__(trace_block(kMfma)) RT_TRACE_WAVES(kBvh, kLds)
             }
             pool_next += (want < avail ? want : avail);
             need = __ballot(!active);
-            if (want <= avail) break;
+            // (a row of the queue can be empty -- a padding pixel -- so a lane may still be without a path here; it asks again)
+            if (want <= avail && !(kQueue && need != 0ull)) break;
         }
         T.mark(0);
         if (!__any(active)) {
@@ -545,6 +594,7 @@ __global__ void __launch_bounds__(trace_block(kMfma)) RT_TRACE_WAVES(kBvh, kLds)
 // accumulation order of main.cpp:124-134; the last batch applies `col /= ns` and quantises.
 struct ResolveArgs {
     const float* samples; float* accum;     // accum: [Q][3] running sums
+    const uint32_t* tile_rank;              // position of every image tile in the work order (the order of the sample buffer); null: image order
     uint32_t Q; int tiles_x; int s_count; int first, last;
     int width, owned_rows, spp;
     float* rgb_mean; int32_t* irgb;
@@ -558,7 +608,7 @@ __global__ void __launch_bounds__(256) k_resolve(const ResolveArgs a)
     const int ty = (int)(tile / (uint32_t)a.tiles_x), tx = (int)(tile - (uint32_t)ty * (uint32_t)a.tiles_x);
     const int i = tx * 8 + (int)(l & 7u), r = ty * 8 + (int)(l >> 3);
     if (i >= a.width || r >= a.owned_rows) return;
-    const float* sp = a.samples + 3 * ((size_t)tile * a.s_count * 64 + l);       // item = (tile * s_count + s) * 64 + l
+    const float* sp = a.samples + 3 * ((size_t)(a.tile_rank ? a.tile_rank[tile] : tile) * a.s_count * 64 + l);       // item = (work tile * s_count + s) * 64 + l
     for (int s = 0; s < a.s_count; ++s, sp += 3 * 64) col = col + mk(sp[0], sp[1], sp[2]);
     if (!a.last) { a.accum[3 * (size_t)q] = col.x; a.accum[3 * (size_t)q + 1] = col.y; a.accum[3 * (size_t)q + 2] = col.z; return; }
     const float inv = 1.0f / (float)a.spp;          // Vec3::operator/=(float), vec3.cpp:109-118
@@ -619,6 +669,12 @@ namespace {
 using TraceKernel = void (*)(const TraceArgs);
 TraceKernel trace_kernel(const TracePlan& t)
 {
+    if (t.queue) {
+        if (t.mfma) return t.lds ? k_trace<true, true, false, true, true> : k_trace<false, true, false, true, true>;
+        if (t.bvh) return t.lds ? k_trace<true, true, true, false, true> : k_trace<false, true, true, false, true>;
+        if (t.lds) return t.plane ? k_trace<true, true, false, false, true> : k_trace<true, false, false, false, true>;
+        return t.plane ? k_trace<false, true, false, false, true> : k_trace<false, false, false, false, true>;
+    }
     if (t.mfma) return t.lds ? k_trace<true, true, false, true> : k_trace<false, true, false, true>;
     if (t.bvh) return t.lds ? k_trace<true, true, true> : k_trace<false, true, true>;
     if (t.lds) return t.plane ? k_trace<true, true> : k_trace<true, false>;
@@ -682,6 +738,7 @@ int trace_prepare(rt_context* ctx, const RenderFrame& f, TracePlan* plan)
     // vector ALU -- the four spheres of the three-sphere test scene: 1.40 against 1.58 ms at 400x225x100)
     t.mfma = !t.bvh && t.plane && ctx->mfma_filter && ctx->n >= 20;
     t.block = trace_block(t.mfma);
+    t.queue = !ctx->primary_lists && ctx->primary_kernel;
     // With the matrix-pipe filter a block keeps 40 + 16 bytes per sphere and 48 KB of mask words in LDS: two blocks per CU (six waves
     // per SIMD) up to 585 spheres, one above.  One block per CU loses more than LDS-resident records gain (600 spheres: 4.98 ms with
     // the records in LDS, 4.17 ms with them read from L2 at full occupancy; 1 536 spheres: 9.89 / 8.18 ms; tools/lds_threshold.py), so
@@ -689,7 +746,7 @@ int trace_prepare(rt_context* ctx, const RenderFrame& f, TracePlan* plan)
     if (t.mfma && t.lds && ctx->max_lds_spheres == 0 &&
         (size_t)ctx->n * kLdsBytesPerSphere + (size_t)((ctx->n + 31) / 32) * 512 + (size_t)(t.block / 64) * kSuperChunkWords * 64 * sizeof(uint32_t) + (size_t)t.block * sizeof(uint32_t) > 80u * 1024u) t.lds = false;
     t.shmem = (t.lds ? (size_t)ctx->n * kLdsBytesPerSphere + (t.mfma ? (size_t)((ctx->n + 31) / 32) * 512 : 0) : 0) + (size_t)(t.block / 64) * (t.bvh ? kBvhStack : kSuperChunkWords) * 64 * sizeof(uint32_t) + (t.mfma ? (size_t)t.block * sizeof(uint32_t) : 0);
-    int& bpc = ctx->trace_blocks_per_cu[t.mfma ? (t.lds ? 7 : 6) : t.bvh ? (t.lds ? 5 : 4) : (t.lds ? 1 : 0) + (t.plane ? 2 : 0)];
+    int& bpc = ctx->trace_blocks_per_cu[(t.queue ? 8 : 0) + (t.mfma ? (t.lds ? 7 : 6) : t.bvh ? (t.lds ? 5 : 4) : (t.lds ? 1 : 0) + (t.plane ? 2 : 0))];
     if (bpc == 0) {
         int nb = 0;
         hipError_t e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, trace_kernel(t), t.block, t.shmem);
@@ -707,15 +764,24 @@ int trace_prepare(rt_context* ctx, const RenderFrame& f, TracePlan* plan)
         HIP_TRY(ctx, hipMalloc(&ctx->d_staging, (lanes / 64) * kStagedFloats * kChunkItems * sizeof(float)));
         ctx->stacks_lanes = lanes;
     }
+    if (t.queue) {
+        const size_t need = (size_t)f.Q * (size_t)f.s_per * kQueueFloats * sizeof(float);
+        if (ctx->queue_bytes < need) {
+            HIP_TRY(ctx, hipStreamSynchronize(st));
+            (void)hipFree(ctx->d_queue); ctx->d_queue = nullptr; ctx->queue_bytes = 0;
+            HIP_TRY(ctx, hipMalloc(&ctx->d_queue, need)); ctx->queue_bytes = need;
+        }
+    }
     const uint32_t n_tiles = f.image_tiles;          // classes, order and lists cover the whole image also when the call renders a share of its tiles
     if (ctx->primary_lists) { const int rc = build_tile_lists(ctx, p, f.owned, st); if (rc != RT_OK) return rc; }
     t.ordered = ctx->tile_ordering;
     if (!t.ordered) return RT_OK;
     if (ctx->tile_cap < n_tiles) {
         HIP_TRY(ctx, hipStreamSynchronize(st));
-        (void)hipFree(ctx->d_tile_cls); (void)hipFree(ctx->d_tile_order); ctx->d_tile_cls = ctx->d_tile_order = nullptr; ctx->tile_cap = 0; ctx->tile_key_valid = false;
+        (void)hipFree(ctx->d_tile_cls); (void)hipFree(ctx->d_tile_order); (void)hipFree(ctx->d_tile_rank); ctx->d_tile_cls = ctx->d_tile_order = ctx->d_tile_rank = nullptr; ctx->tile_cap = 0; ctx->tile_key_valid = false;
         HIP_TRY(ctx, hipMalloc(&ctx->d_tile_cls, (size_t)n_tiles * sizeof(uint32_t)));
         HIP_TRY(ctx, hipMalloc(&ctx->d_tile_order, (size_t)n_tiles * sizeof(uint32_t)));
+        HIP_TRY(ctx, hipMalloc(&ctx->d_tile_rank, (size_t)n_tiles * sizeof(uint32_t)));
         ctx->tile_cap = n_tiles;
     }
     const rt_context::TileKey key{ ctx->scene_version, ctx->camera_version, p->width, p->height, p->band_rows, p->band_first, p->band_step, p->tmin };
@@ -724,7 +790,7 @@ int trace_prepare(rt_context* ctx, const RenderFrame& f, TracePlan* plan)
     ta.geom = ctx->d_geom; ta.aux = ctx->d_aux; ta.n = ctx->n; ta.cam = ctx->cam; ta.tmin = p->tmin;
     ta.ig.width = p->width; ta.ig.height = p->height; ta.ig.band_rows = p->band_rows; ta.ig.band_first = p->band_first; ta.ig.band_step = p->band_step;
     ta.ig.owned_rows = f.owned; ta.ig.tiles_x = f.tiles_x; ta.ig.Q = n_tiles * 64u; ta.ig.s_begin = 0; ta.ig.s_count = 1; ta.ig.tile_order = nullptr;
-    ta.tiles = n_tiles; ta.cls = ctx->d_tile_cls; ta.order = ctx->d_tile_order;
+    ta.tiles = n_tiles; ta.cls = ctx->d_tile_cls; ta.order = ctx->d_tile_order; ta.rank = ctx->d_tile_rank;
     if (ctx->primary_lists) hipLaunchKernelGGL(k_tile_class_from_lists, dim3((n_tiles + 255u) / 256u), dim3(256), 0, st, ctx->d_tile_lists, ctx->d_aux, n_tiles, ctx->d_tile_cls);
     else hipLaunchKernelGGL(k_tile_class, dim3((n_tiles * 8u + 255u) / 256u), dim3(256), 0, st, ta);
     hipLaunchKernelGGL(k_tile_order, dim3(1), dim3(1024), 0, st, ta);
@@ -741,11 +807,12 @@ int trace_batch(rt_context* ctx, const RenderFrame& f, const TracePlan& t, const
     a.width = p->width; a.height = p->height; a.max_depth = p->max_depth; a.tmin = p->tmin;
     a.k0 = (uint32_t)p->seed; a.k1 = (uint32_t)(p->seed >> 32);
     a.band_rows = p->band_rows; a.band_first = p->band_first; a.band_step = p->band_step; a.owned_rows = f.owned;
-    a.tiles_x = f.tiles_x; a.Q = (uint32_t)f.Q; a.share_first = f.share_first; a.share_step = f.share_step; a.share_compact = f.tile_output ? 1 : 0; a.s_begin = b.s0; a.s_count = b.sc; a.total_items = (uint32_t)(f.Q * b.sc);
+    a.tiles_x = f.tiles_x; a.Q = (uint32_t)f.Q; a.share_first = f.share_first; a.share_step = f.share_step; a.s_begin = b.s0; a.s_count = b.sc; a.total_items = (uint32_t)(f.Q * b.sc);
     a.samples = ctx->d_samples; a.ray_counter = ctx->d_rays; a.work_counter = ctx->d_work;
     a.stacks = ctx->d_stacks; a.stack_stride = (uint32_t)ctx->stacks_lanes; a.staging = ctx->d_staging;
     a.tile_order = t.ordered ? ctx->d_tile_order : nullptr;
     a.tile_lists = ctx->primary_lists ? ctx->d_tile_lists : nullptr;
+    a.queue = t.queue ? ctx->d_queue : nullptr;
     a.bvh.nodes = ctx->d_bvh_nodes; a.bvh.leaf_index = ctx->d_bvh_leaf; a.bvh.big = ctx->d_bvh_big; a.bvh.n_big = ctx->bvh_n_big; a.bvh.geom = ctx->d_geom;
     // Chunk size.  A chunk costs its wave a fixed amount (the atomic, and the wave's live paths standing still while it stages the
     // chunk's camera rays), and what a wave still holds when the counter runs dry is proportional to the chunk: the sum is smallest
@@ -766,6 +833,7 @@ int trace_batch(rt_context* ctx, const RenderFrame& f, const TracePlan& t, const
     const dim3 grid((unsigned)(want_blocks < cap_blocks ? want_blocks : cap_blocks)), block(t.block);
     // the first chunk of every launched wave is implied by its index; the counter hands out what follows
     HIP_TRY(ctx, hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(ctx->d_work), (int)(grid.x * (unsigned)(t.block / 64) * (unsigned)a.chunk_items), 1, f.st));
+    if (t.queue) hipLaunchKernelGGL(k_primary, dim3((a.total_items + 255u) / 256u), dim3(256), 0, f.st, a);
     hipLaunchKernelGGL(trace_kernel(t), grid, block, t.shmem, f.st, a);
     HIP_TRY(ctx, hipGetLastError());
     return RT_OK;
@@ -787,6 +855,8 @@ int resolve_batch(rt_context* ctx, const RenderFrame& f, const SampleBatch& b)
     r.samples = ctx->d_samples; r.accum = ctx->d_accum; r.Q = (uint32_t)f.Q; r.tiles_x = f.tiles_x; r.s_count = b.sc;
     r.first = (b.index == 0); r.last = (b.index == f.batches - 1); r.width = f.p->width; r.owned_rows = f.owned; r.spp = f.p->spp;
     r.rgb_mean = f.d_rgb_mean; r.irgb = f.d_irgb;
+    // (the wavefront mode fills the sample buffer in image order, the megakernel in its work order)
+    r.tile_rank = f.p->mode != RT_MODE_WAVEFRONT && ctx->tile_ordering ? ctx->d_tile_rank : nullptr;
     hipLaunchKernelGGL(k_resolve, dim3((unsigned)((f.Q + 255) / 256)), dim3(256), 0, f.st, r);
     HIP_TRY(ctx, hipGetLastError());
     return RT_OK;
