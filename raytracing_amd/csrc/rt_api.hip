@@ -320,7 +320,7 @@ int render_impl(rt_context* ctx, const char* who, const rt_params* p, int share_
             // (with the camera rays of a batch queued by a kernel of their own -- 32 bytes per item -- that queue has a cap too)
             if (p->mode != RT_MODE_WAVEFRONT && !ctx->primary_lists && ctx->primary_kernel && per_batch > ctx->queue_cap / (f.Q * 32)) per_batch = ctx->queue_cap / (f.Q * 32);
             if (per_batch > (1ull << 31) / f.Q) per_batch = (1ull << 31) / f.Q;
-            if (per_batch == 0) return fail(ctx, RT_ERR_TOO_LARGE, "%s: %llu pixels in one call exceed the sample-buffer limit; split the image into bands", who, (unsigned long long)f.Q);
+            if (per_batch == 0) return fail(ctx, RT_ERR_TOO_LARGE, "%s: %llu pixels in one call exceed the sample-buffer (or camera-ray queue) limit; split the image into bands", who, (unsigned long long)f.Q);
             f.batches = (int)((p->spp + per_batch - 1) / per_batch);
             f.s_per = (p->spp + f.batches - 1) / f.batches;
             const size_t need = (size_t)f.Q * f.s_per * 12;

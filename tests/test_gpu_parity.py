@@ -841,6 +841,61 @@ def test_sample_batches_accumulate_in_sample_order(monkeypatch, mode):
     r.close(); tiny.close()
 
 
+@pytest.mark.parametrize("mode", [R.MODE_MEGAKERNEL, R.MODE_BVH])
+def test_camera_rays_from_their_own_kernel(monkeypatch, mode):
+    """With camera rays swept like every other ray, the camera rays of a sample batch come from a kernel of their own, through a
+    queue in device memory (main.cpp:118-133 with Camera::GetRay, camera.cpp:46-53).  Same image, ray count and counters as with
+    the rays generated inside the render kernel and as the golden image: on a ragged size (padding pixels leave empty queue rows),
+    on interleaved rows, over several batches forced by a small queue cap, and through tile shares."""
+    import torch
+    from raytracing_amd import dist as rdist
+    m = _meta()["philox_final_40x30x16_ap0"]
+    want = np.load(os.path.join(G, "img_philox_final_40x30x16_ap0.npy"))
+    monkeypatch.setenv("RT_AMD_QUEUE_KB", "256")             # 40x32 padded pixels x 32 B = 40 KB per sample: 6 samples per batch (104x64 further down: one)
+    queued = R.Renderer(0, camera_ray_lists=False)
+    monkeypatch.delenv("RT_AMD_QUEUE_KB")
+    monkeypatch.setenv("RT_AMD_PRIMARY_KERNEL", "0")
+    staged = R.Renderer(0, camera_ray_lists=False)
+    monkeypatch.delenv("RT_AMD_PRIMARY_KERNEL")
+    for r in (queued, staged):
+        _setup(r, m)
+        rgb, irgb, rays, _ = r.render(r.params(m["nx"], m["ny"], m["ns"], seed=m["seed"], mode=mode))
+        assert rays == m["rays"] and r.counters() == (m["rays"], m["hits"], m["scatters"])
+        assert mismatch(rgb, want) == 0
+    # three tile shares, several batches each
+    p = queued.params(m["nx"], m["ny"], m["ns"], seed=m["seed"], mode=mode)
+    tiles, ids, total = [], [], 0
+    for k in range(3):
+        cnt = queued.owned_tiles(p, k, 3)
+        t = torch.zeros((cnt, 64, 3), dtype=torch.float32, device="cuda"); i = torch.zeros(cnt, dtype=torch.int32, device="cuda")
+        queued.render_tiles_device(p, k, 3, d_rgb_mean_tiles=t.data_ptr(), d_tile_ids=i.data_ptr())
+        total += queued.stats()[0]
+        tiles.append(t); ids.append(i)
+    img = rdist.assemble_tiles(torch.cat(tiles), torch.cat(ids), m["nx"], m["ny"]).cpu().numpy()
+    assert total == m["rays"] and mismatch(img, want) == 0
+    # ragged sizes, interleaved rows, a wide lens: queue against in-kernel staging against the literal kernel
+    for r in (queued, staged):
+        r.upload_scene(R.final_scene_table())
+        r.set_camera(R.final_camera(101, 59))
+    for kw in (dict(), dict(band_rows=3, band_first=1, band_step=2), dict(band_rows=1, band_first=6, band_step=7)):
+        a = queued.render(queued.params(101, 59, 7, seed=3, mode=mode, **kw))
+        b = staged.render(staged.params(101, 59, 7, seed=3, mode=mode, **kw))
+        c = staged.render(staged.params(101, 59, 7, seed=3, mode=R.MODE_PIXEL, **kw))
+        assert a[2] == b[2] == c[2] and a[2] > 0
+        assert np.array_equal(a[0].view(np.uint32), b[0].view(np.uint32)) and np.array_equal(a[0].view(np.uint32), c[0].view(np.uint32))
+        assert np.array_equal(a[1], c[1])
+    # a queue cap below one sample of the image is an error, not a crash
+    monkeypatch.setenv("RT_AMD_QUEUE_KB", "16")
+    tiny = R.Renderer(0, camera_ray_lists=False)
+    monkeypatch.delenv("RT_AMD_QUEUE_KB")
+    _setup(tiny, m)
+    with pytest.raises(R.RtError) as e:
+        tiny.render(tiny.params(m["nx"], m["ny"], m["ns"], seed=m["seed"], mode=mode))
+    assert e.value.code == -5
+    for r in (queued, staged, tiny):
+        r.close()
+
+
 def _ref_band():
     sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "oracle"))
     import ref_band
