@@ -257,17 +257,20 @@ def setup_scene(rt, scene_name, width, height):
 def roofline_block(args, n_spheres, rays_per_launch, kernel_ms, prof):
     """The FP32 vector-ALU roofline of the dominant kernel, k_trace on the brute-force path: every ray against every sphere.
     `achieved` prices each ray-sphere test at the reference's 18 flop (sphere.cpp:17-25) plus 150 flop per ray for hit record
-    and scatter: rays x (18 x spheres + 150) / kernel time.  The kernel makes every one of those tests, but as a conservative
-    filter (the pair's dot product on the bf16 matrix pipe, verdict and accumulate on the vector ALU) followed by the reference's
-    own arithmetic on the few survivors, so it executes fewer FP32 operations than it is credited with: `executed_*`, from the
-    profiled instruction counters, is what the vector ALU did."""
+    and scatter: rays x (18 x spheres + 150) / kernel time (the time of ALL kernels of the step: camera rays, k_trace, resolve).
+    The kernel makes every one of those tests, but as a conservative filter (the pair's dot product on the bf16 matrix pipe,
+    verdict and accumulate on the vector ALU) followed by the reference's own arithmetic on the few survivors, so it executes
+    fewer FP32 operations than it is credited with -- `executed_*`, from the profiled instruction counters, is what the vector
+    ALU did -- and, since the dot products do not run on the pipe whose peak is the denominator, `frac` can pass 1."""
     flop_per_ray = FLOP_PER_TEST * n_spheres + FLOP_PER_RAY_EXTRA
     achieved = rays_per_launch * flop_per_ray / (kernel_ms * 1e-3) / 1e12
     block = {"bound": "valu", "achieved": achieved, "peak": PEAK_FP32_VALU_TFLOPS, "unit": "TFLOP/s", "frac": achieved / PEAK_FP32_VALU_TFLOPS,
-             "frac_is": "rays x (18 x spheres + 150) flop per launch / kernel time / peak, every ray tested against every sphere (brute force); "
-                        "executed_frac is what the vector ALU executed",
+             "frac_is": "rays x (18 x spheres + 150) flop per launch / time of all kernels of the step / FP32 vector peak, every ray tested against every "
+                        "sphere (brute force).  Above 1 means faster than a literal FP32 vector-ALU implementation could be at its peak: the "
+                        "18-flop test's dot product runs on the bf16 matrix pipe, which that peak does not count.  executed_frac is what the "
+                        "vector ALU executed, valu_issue_frac how busy its issue port was",
              "peak_sustained_measured": SUSTAINED_FP32_FMA_TFLOPS, "frac_of_sustained": achieved / SUSTAINED_FP32_FMA_TFLOPS,
-             "kernel": {"megakernel": "k_trace", "wavefront": "k_wf_intersect + k_wf_shade", "pixel": "k_render_mega", "bvh": "k_trace (hierarchy walk)"}[args.mode],
+             "kernel": {"megakernel": "k_trace (timed together with k_primary before it and k_resolve after it)", "wavefront": "k_wf_intersect + k_wf_shade", "pixel": "k_render_mega", "bvh": "k_trace (hierarchy walk)"}[args.mode],
              "flop_per_ray": flop_per_ray, "traffic": None, "executed_achieved": None, "executed_frac": None,
              "note": "FP32 vector-ALU bound: the pair test's dot product runs on the bf16 matrix pipe (2 of ~7 SIMD cycles per sphere and wave), "
                      "verdict, accumulate, exact passes and shading on the vector ALU; HBM traffic is small"}

@@ -81,7 +81,7 @@ void rt_destroy(rt_context* ctx)
     if (ctx->pending) (void)hipStreamSynchronize(ctx->last_stream);
     (void)hipFree(ctx->d_geom); (void)hipFree(ctx->d_mat); (void)hipFree(ctx->d_aux); (void)hipFree(ctx->d_rays); (void)hipFree(ctx->d_ppm_scratch); (void)hipFree(ctx->d_out_rgb); (void)hipFree(ctx->d_out_irgb);
     (void)hipFree(ctx->d_bvh_nodes); (void)hipFree(ctx->d_bvh_leaf); (void)hipFree(ctx->d_bvh_big);
-    (void)hipFree(ctx->d_frec); (void)hipFree(ctx->d_prec); (void)hipFree(ctx->d_arec); (void)hipFree(ctx->d_force); (void)hipFree(ctx->d_samples); (void)hipFree(ctx->d_accum); (void)hipFree(ctx->d_work); (void)hipFree(ctx->d_stacks); (void)hipFree(ctx->d_staging); (void)hipFree(ctx->d_tile_cls); (void)hipFree(ctx->d_tile_order); (void)hipFree(ctx->d_tile_rank); (void)hipFree(ctx->d_queue); (void)hipFree(ctx->d_tile_lists);
+    (void)hipFree(ctx->d_frec); (void)hipFree(ctx->d_prec); (void)hipFree(ctx->d_arec); (void)hipFree(ctx->d_force); (void)hipFree(ctx->d_samples); (void)hipFree(ctx->d_accum); (void)hipFree(ctx->d_work); (void)hipFree(ctx->d_stacks); (void)hipFree(ctx->d_staging); (void)hipFree(ctx->d_tile_cls); (void)hipFree(ctx->d_tile_order); (void)hipFree(ctx->d_tile_rank); (void)hipFree(ctx->d_queue); (void)hipFree(ctx->d_seg_count); (void)hipFree(ctx->d_tile_lists);
     (void)hipFree(ctx->wf_ray); (void)hipFree(ctx->wf_pixsmp); (void)hipFree(ctx->wf_depth); (void)hipFree(ctx->wf_hit_t); (void)hipFree(ctx->wf_hit_idx);
     (void)hipFree(ctx->wf_stacks); (void)hipFree(ctx->wf_q[0]); (void)hipFree(ctx->wf_q[1]); (void)hipFree(ctx->wf_n);
     if (ctx->ev0) (void)hipEventDestroy(ctx->ev0);
@@ -317,8 +317,9 @@ int render_impl(rt_context* ctx, const char* who, const rt_params* p, int share_
             // sample batches: the per-batch sample buffer stays below 16 GiB (of 288 GB of HBM) and item ids below 2^31;
             // every batch ends with the drain of its longest paths, so fewer, larger batches are better
             uint64_t per_batch = ctx->sample_buffer_cap / (f.Q * 12);
-            // (with the camera rays of a batch queued by a kernel of their own -- 32 bytes per item -- that queue has a cap too)
-            if (p->mode != RT_MODE_WAVEFRONT && !ctx->primary_lists && ctx->primary_kernel && per_batch > ctx->queue_cap / (f.Q * 32)) per_batch = ctx->queue_cap / (f.Q * 32);
+            // (with the camera rays of a batch queued by a kernel of their own -- 32 or 48 bytes per item -- that queue has a cap too)
+            const uint64_t row_bytes = ctx->primary_lists ? 48 : 32;
+            if (p->mode != RT_MODE_WAVEFRONT && ctx->primary_kernel && per_batch > ctx->queue_cap / (f.Q * row_bytes)) per_batch = ctx->queue_cap / (f.Q * row_bytes);
             if (per_batch > (1ull << 31) / f.Q) per_batch = (1ull << 31) / f.Q;
             if (per_batch == 0) return fail(ctx, RT_ERR_TOO_LARGE, "%s: %llu pixels in one call exceed the sample-buffer (or camera-ray queue) limit; split the image into bands", who, (unsigned long long)f.Q);
             f.batches = (int)((p->spp + per_batch - 1) / per_batch);

@@ -30,8 +30,10 @@ struct rt_context {
     unsigned int* d_work = nullptr;
     uint16_t* d_stacks = nullptr; size_t stacks_lanes = 0;
     float* d_staging = nullptr;
-    // camera rays of one sample batch as k_primary leaves them for k_trace (32 bytes per item), when camera rays are swept
-    float* d_queue = nullptr; size_t queue_bytes = 0; uint64_t queue_cap = 16ull << 30; bool primary_kernel = true;
+    // camera rays of one sample batch as k_primary leaves them for k_trace (32 bytes per item) when camera rays are swept; with per-tile
+    // lists the second rays k_primary_lists leaves (up to 48 bytes per item) and how many per segment
+    float* d_queue = nullptr; size_t queue_bytes = 0; uint64_t queue_cap = 24ull << 30; bool primary_kernel = true;
+    uint32_t* d_seg_count = nullptr; size_t seg_cap = 0;
     uint32_t* d_tile_cls = nullptr; uint32_t* d_tile_order = nullptr; uint32_t* d_tile_rank = nullptr; size_t tile_cap = 0;   // work order of the tiles of the current call (position -> image tile) and its inverse
     bool tile_ordering = true;
     uint32_t* d_tile_lists = nullptr; size_t tile_list_cap = 0;    // per tile: the spheres its camera rays can meet (k_tile_lists)
@@ -43,7 +45,7 @@ struct rt_context {
     uint32_t wf_P = 0; float* wf_ray = nullptr; uint32_t* wf_pixsmp = nullptr; int* wf_depth = nullptr; float* wf_hit_t = nullptr; int* wf_hit_idx = nullptr;
     uint16_t* wf_stacks = nullptr; uint32_t* wf_q[2] = { nullptr, nullptr }; uint32_t* wf_n = nullptr;
     int wf_blocks_per_cu[4] = { 0, 0, 0, 0 };
-    int num_cu = 0; int trace_blocks_per_cu[16] = {};
+    int num_cu = 0; int trace_blocks_per_cu[24] = {};
     // sphere hierarchy of RT_MODE_BVH (rt_bvh.hpp), rebuilt with every scene upload
     float4* d_bvh_nodes = nullptr; uint32_t* d_bvh_leaf = nullptr; uint32_t* d_bvh_big = nullptr; int bvh_n_big = 0, bvh_depth = 0, bvh_nodes = 0;
     bool have_camera = false; CameraD cam{};
@@ -74,7 +76,7 @@ struct RenderFrame {
 };
 struct SampleBatch { int index, s0, sc; };
 // What trace_prepare settles once per call for the batches of k_trace.
-struct TracePlan { bool lds, plane, bvh, mfma, ordered, queue; size_t shmem; int blocks_per_cu, block; };
+struct TracePlan { bool lds, plane, bvh, mfma, ordered; int queue; size_t shmem; int blocks_per_cu, block; };
 
 #define RT_HIDDEN __attribute__((visibility("hidden")))
 int pixel_render(rt_context* ctx, const RenderFrame& f) RT_HIDDEN;                                              // rt_pixel.hip

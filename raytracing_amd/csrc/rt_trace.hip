@@ -48,7 +48,9 @@ struct TraceArgs {
     BvhScene bvh;                         // RT_MODE_BVH only
     uint16_t* stacks; uint32_t stack_stride;   // hit-index stacks in HBM: entry k of lane g at stacks[k * stack_stride + g]
     const uint32_t* tile_lists;           // per image tile: the spheres its camera rays can meet (k_tile_lists); null: every camera ray is swept
-    float* queue;                         // the camera ray of every item of the batch, row i = item i (k_primary); k_trace<..., kQueue = true> reads it
+    float* queue;                         // kQueue 1: the camera ray of every item of the batch, row i = item i, 32 bytes (k_primary);
+                                          // kQueue 2: per segment of chunk_items items the rows stage_chunk leaves, 48 bytes each, from row segment * chunk_items on (k_primary_lists)
+    uint32_t* seg_count; uint32_t n_segments;      // kQueue 2: rows written per segment
 };
 
 // ============================================================================ work order of the tiles
@@ -304,7 +306,119 @@ __global__ void __launch_bounds__(256) k_primary(const TraceArgs a)
 #endif
 constexpr bool kWidePhilox = RT_WIDE_PHILOX != 0;     // the staging phase of k_trace has the registers for 64-bit products
 constexpr int kUnresolved = -2;             // staging row 9: the staged ray is the camera ray itself (no list for its tile), not the path's second ray
-template <bool kLds, bool kPlane, bool kBvh = false, bool kMfma = false, bool kQueue = false>
+// The camera rays of the items [g, claim_end) (whole rows of 64: one tile at one sample each), all lanes busy, written as rows of
+// kStagedFloats floats from `staged` on; returns how many rows were written.  With per-tile sphere lists this is also the first
+// level of Color() for those rays (see below): finished paths store their sample and leave no row.  Runs inside k_trace for the
+// chunk a wave has reserved, and as the body of k_primary_lists for one segment of a batch.
+template <bool kLds>
+__device__ __forceinline__ uint32_t stage_chunk(const TraceArgs& a, const ItemGeometry& ig, uint32_t g, uint32_t claim_end, int lane, float fnx, float fny,
+                                                const float4* s_geom, const float4* s_mat, const Aux* s_aux, float* staged,
+                                                uint32_t& rays, uint32_t& misses, SecTimer& T)
+{
+    uint32_t kept = 0;
+    // the list of the tile the current row belongs to: lane q holds candidate q (index and exact record), fetched when the tile changes
+    uint32_t list_tile = 0xffffffffu, cnt = kNoTileList; int cand = 0; float4 crec = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+    for (uint32_t row = g; row < claim_end; row += 64u) {        // 64 items: one tile at one sample
+        const uint32_t it = row + (uint32_t)lane;
+        uint32_t gp = 0xffffffffu, gs = 0u, gstore = 0u; int i = 0, j = 0;
+        RayD gr; gr.o = mk(0, 0, 0); gr.d = mk(0, 0, 0);
+        bool keep = decode_item(ig, it, gp, gs, i, j, gstore);         // padding pixels of edge tiles are dropped here
+        if (keep) gr = camera_ray<kWidePhilox>(a.cam, gp, gs, i, j, fnx, fny, a.k0, a.k1);
+        T.mark(8);
+        // The first level of Color() for the camera ray, here, where the 64 lanes hold the rays of one tile: the closest
+        // hit over the tile's list (all lanes on the same few spheres, records as scalar loads, ascending sphere order
+        // with strict comparisons: HittableList::Hit's answer), then the shading step.  What is staged is the SECOND
+        // ray of the path with the index of the sphere it left; a path that ends here stores its sample and takes no lane.
+        int first = kUnresolved;
+        if (a.tile_lists) {
+            const uint32_t ts = (uint32_t)__builtin_amdgcn_readfirstlane((int)(row >> 6));
+            const uint32_t work_tile = ts / (uint32_t)a.s_count;
+            if (work_tile != list_tile) {
+                list_tile = work_tile;
+                const uint32_t tile = image_tile(ig, work_tile);
+                const uint32_t* list = a.tile_lists + (size_t)tile * kTileListWords;
+                cnt = (uint32_t)__builtin_amdgcn_readfirstlane((int)list[0]);
+                if (cnt != kNoTileList) {
+                    cand = (uint32_t)lane < cnt ? (int)list[1 + lane] : 0;
+                    crec = a.geom[cand];            // (centre, r * r)
+                }
+            }
+            if (cnt != kNoTileList) {
+                const float qa = dot(gr.d, gr.d);
+                float pre_t = FLT_MAX; int pre_k = -1;
+                for (uint32_t q = 0; q < cnt; ++q) {
+                    const int k = __builtin_amdgcn_readlane(cand, (int)q);
+                    const V3 cq = mk(__builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, crec.x), (int)q)),
+                                     __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, crec.y), (int)q)),
+                                     __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, crec.z), (int)q)));
+                    const float r2 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, crec.w), (int)q));
+                    const V3 oc = gr.o - cq;
+                    const float b = dot(oc, gr.d);
+                    const float cc = dot(oc, oc) - r2;
+                    const float desc = b * b - qa * cc;
+                    if (desc > 0.0f) {
+                        const float sq = sqrtf(desc);
+                        float temp = (-b - sq) / qa;
+                        if (!(temp < pre_t && temp > a.tmin)) temp = (-b + sq) / qa;
+                        if (temp < pre_t && temp > a.tmin) { pre_t = temp; pre_k = k; }
+                    }
+                }
+                T.mark(9);
+                rays += (uint32_t)__popcll(__ballot(keep)); misses += (uint32_t)__popcll(__ballot(keep && pre_k < 0));
+                if (keep) {
+                    int d0 = 0; V3 sample;
+                    SecTimer untimed;            // (diagnostic build: the staging phase is timed as a whole)
+                    KeyedUniformsT<kWidePhilox> UW; UW.k0 = a.k0; UW.k1 = a.k1;
+                    const bool done = shade_step<kLds, true>(gr, d0, pre_t, pre_k, gp, gs, a.max_depth, UW, s_geom, s_mat, s_aux, a.geom, a.mat, a.aux, nullptr, 0, sample, untimed);
+                    first = pre_k;
+                    if (done) {
+                        float* o = a.samples + (size_t)gstore * 3;
+                        o[0] = sample.x; o[1] = sample.y; o[2] = sample.z;
+                        keep = false;
+                    }
+                }
+            }
+        }
+        T.mark(10);
+        const unsigned long long km = __ballot(keep);
+        const uint32_t slot = kept + __builtin_amdgcn_mbcnt_hi((uint32_t)(km >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)km, 0u));
+        kept += (uint32_t)__popcll(km);
+        if (keep) {
+            float* rec = staged + (size_t)slot * kStagedFloats;
+            v4f ra, rb, rc;
+            ra.x = gr.o.x; ra.y = gr.o.y; ra.z = gr.o.z; ra.w = gr.d.x;
+            rb.x = gr.d.y; rb.y = gr.d.z; rb.z = __uint_as_float(gp); rb.w = __uint_as_float(gs);
+            rc.x = __uint_as_float(gstore); rc.y = __int_as_float(first); rc.z = 0.0f; rc.w = 0.0f;
+            *reinterpret_cast<v4f*>(rec) = ra; *reinterpret_cast<v4f*>(rec + 4) = rb; *reinterpret_cast<v4f*>(rec + 8) = rc;
+        }
+    }
+    return kept;
+}
+
+// With per-tile sphere lists the first level of Color() is part of what happens before k_trace as well: every wave of this kernel
+// takes whole segments of a batch (chunk_items consecutive items: a few samples of one tile), runs stage_chunk on them -- camera
+// rays, closest hit over the tile's list, first shading step, 64 lanes on rays of one kind -- and leaves the second rays of the
+// paths that go on as dense rows at the start of the segment's part of the queue, their number in seg_count.  k_trace reserves
+// segments instead of chunks of items.  No atomics: segments are dealt to waves by index, counters are summed per wave.
+__global__ void __launch_bounds__(256) k_primary_lists(const TraceArgs a)
+{
+    const int lane = threadIdx.x & 63;
+    const uint32_t n_waves = gridDim.x * 4u;
+    ItemGeometry ig; ig.width = a.width; ig.height = a.height; ig.band_rows = a.band_rows; ig.band_first = a.band_first; ig.band_step = a.band_step;
+    ig.owned_rows = a.owned_rows; ig.tiles_x = a.tiles_x; ig.Q = a.Q; ig.s_begin = a.s_begin; ig.s_count = a.s_count; ig.tile_order = a.tile_order; ig.share_first = a.share_first; ig.share_step = a.share_step;
+    uint32_t rays = 0, misses = 0;
+    SecTimer untimed;
+    for (uint32_t seg = (uint32_t)__builtin_amdgcn_readfirstlane((int)(blockIdx.x * 4u + (threadIdx.x >> 6))); seg < a.n_segments; seg += n_waves) {
+        const uint32_t g = seg * (uint32_t)a.chunk_items;
+        const uint32_t end = (a.total_items - g < (uint32_t)a.chunk_items) ? a.total_items : g + (uint32_t)a.chunk_items;
+        const uint32_t kept = stage_chunk<false>(a, ig, g, end, lane, (float)a.width, (float)a.height, nullptr, nullptr, nullptr,
+                                                 a.queue + (size_t)g * kStagedFloats, rays, misses, untimed);
+        if (lane == 0) a.seg_count[seg] = kept;
+    }
+    if (lane == 0 && rays) { atomicAdd(a.ray_counter, (unsigned long long)rays); atomicAdd(a.ray_counter + 1, (unsigned long long)misses); }
+}
+
+template <bool kLds, bool kPlane, bool kBvh = false, bool kMfma = false, int kQueue = 0>
 __global__ void __launch_bounds__(trace_block(kMfma)) RT_TRACE_WAVES(kBvh, kLds) k_trace(const TraceArgs a)
 {
     constexpr int kTraceBlock = trace_block(kMfma);       // (shadows the 512 of the other kernels inside this one)
@@ -358,7 +472,7 @@ __global__ void __launch_bounds__(trace_block(kMfma)) RT_TRACE_WAVES(kBvh, kLds)
     uint32_t rays = 0, misses = 0;             // wave-uniform: queries and sky misses of the whole wave
     uint32_t pool_next = 0, pool_end = 0, pool_base = 0;      // wave-uniform: the staged rows not yet handed out are pool_next - pool_base .. pool_end - pool_base
     uint32_t claim_end = 0;                                   // wave-uniform: end of the items this wave reserved last
-    float* staged = a.staging + ((size_t)blockIdx.x * (kTraceBlock / 64) + wave) * (kStagedFloats * kChunkItems);
+    float* staged = kQueue == 2 ? a.queue : a.staging + ((size_t)blockIdx.x * (kTraceBlock / 64) + wave) * (kStagedFloats * kChunkItems);       // (kQueue 2: rows are addressed from the start of the queue, pool_base stays 0)
     bool exhausted = false;                    // wave-uniform
     bool first_chunk = true;                   // wave-uniform
     const float fnx = (float)a.width, fny = (float)a.height;
@@ -378,6 +492,18 @@ __global__ void __launch_bounds__(trace_block(kMfma)) RT_TRACE_WAVES(kBvh, kLds)
         // ---------------------------------------------------------------- hand out new items
         unsigned long long need = __ballot(!active);
         while (need != 0ull && !(exhausted && pool_next == pool_end)) {
+            if constexpr (kQueue == 2) {
+                if (pool_next == pool_end) {
+                    // one segment of the queue: its rows are dense from the segment's first row on
+                    unsigned int sg = 0;
+                    if (first_chunk) { first_chunk = false; sg = blockIdx.x * (uint32_t)(kTraceBlock / 64) + (uint32_t)wave; }
+                    else { if (lane == 0) sg = atomicAdd(a.work_counter, 1u); sg = __builtin_amdgcn_readfirstlane(sg); }
+                    if (sg >= a.n_segments) { exhausted = true; break; }
+                    pool_next = sg * (uint32_t)a.chunk_items;
+                    pool_end = pool_next + (uint32_t)__builtin_amdgcn_readfirstlane((int)a.seg_count[sg]);
+                    if (pool_next == pool_end) continue;           // nothing of this segment goes on
+                }
+            } else
             if (pool_next == pool_end) {
                 unsigned int g = 0;
                 // Chunks shrink towards the end of the work (down to a floor that keeps the hand-out cheap next to
@@ -406,7 +532,7 @@ __global__ void __launch_bounds__(trace_block(kMfma)) RT_TRACE_WAVES(kBvh, kLds)
                 if (g >= a.total_items) { exhausted = true; break; }
                 pool_next = g; pool_base = g;
                 claim_end = (a.total_items - g < take) ? a.total_items : g + take;
-                if constexpr (kQueue) {
+                if constexpr (kQueue == 1) {
                     pool_end = claim_end;          // the rows of the queue are the items themselves
                 } else {
                 // Generate the camera rays of the whole chunk now, all lanes busy, into this wave's staging
@@ -416,83 +542,7 @@ __global__ void __launch_bounds__(trace_block(kMfma)) RT_TRACE_WAVES(kBvh, kLds)
 #ifdef RT_STAGE_PRIO
                 set_wave_priority(RT_STAGE_PRIO);
 #endif
-                uint32_t kept = 0;
-                // the list of the tile the current row belongs to: lane q holds candidate q (index and exact record), fetched when the tile changes
-                uint32_t list_tile = 0xffffffffu, cnt = kNoTileList; int cand = 0; float4 crec = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
-                for (uint32_t row = g; row < claim_end; row += 64u) {        // 64 items: one tile at one sample
-                    const uint32_t it = row + (uint32_t)lane;
-                    uint32_t gp = 0xffffffffu, gs = 0u, gstore = 0u; int i = 0, j = 0;
-                    RayD gr; gr.o = mk(0, 0, 0); gr.d = mk(0, 0, 0);
-                    bool keep = decode_item(ig, it, gp, gs, i, j, gstore);         // padding pixels of edge tiles are dropped here
-                    if (keep) gr = camera_ray<kWidePhilox>(a.cam, gp, gs, i, j, fnx, fny, a.k0, a.k1);
-                    T.mark(8);
-                    // The first level of Color() for the camera ray, here, where the 64 lanes hold the rays of one tile: the closest
-                    // hit over the tile's list (all lanes on the same few spheres, records as scalar loads, ascending sphere order
-                    // with strict comparisons: HittableList::Hit's answer), then the shading step.  What is staged is the SECOND
-                    // ray of the path with the index of the sphere it left; a path that ends here stores its sample and takes no lane.
-                    int first = kUnresolved;
-                    if (a.tile_lists) {
-                        const uint32_t ts = (uint32_t)__builtin_amdgcn_readfirstlane((int)(row >> 6));
-                        const uint32_t work_tile = ts / (uint32_t)a.s_count;
-                        if (work_tile != list_tile) {
-                            list_tile = work_tile;
-                            const uint32_t tile = image_tile(ig, work_tile);
-                            const uint32_t* list = a.tile_lists + (size_t)tile * kTileListWords;
-                            cnt = (uint32_t)__builtin_amdgcn_readfirstlane((int)list[0]);
-                            if (cnt != kNoTileList) {
-                                cand = (uint32_t)lane < cnt ? (int)list[1 + lane] : 0;
-                                crec = a.geom[cand];            // (centre, r * r)
-                            }
-                        }
-                        if (cnt != kNoTileList) {
-                            const float qa = dot(gr.d, gr.d);
-                            float pre_t = FLT_MAX; int pre_k = -1;
-                            for (uint32_t q = 0; q < cnt; ++q) {
-                                const int k = __builtin_amdgcn_readlane(cand, (int)q);
-                                const V3 cq = mk(__builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, crec.x), (int)q)),
-                                                 __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, crec.y), (int)q)),
-                                                 __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, crec.z), (int)q)));
-                                const float r2 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, crec.w), (int)q));
-                                const V3 oc = gr.o - cq;
-                                const float b = dot(oc, gr.d);
-                                const float cc = dot(oc, oc) - r2;
-                                const float desc = b * b - qa * cc;
-                                if (desc > 0.0f) {
-                                    const float sq = sqrtf(desc);
-                                    float temp = (-b - sq) / qa;
-                                    if (!(temp < pre_t && temp > a.tmin)) temp = (-b + sq) / qa;
-                                    if (temp < pre_t && temp > a.tmin) { pre_t = temp; pre_k = k; }
-                                }
-                            }
-                            T.mark(9);
-                            rays += (uint32_t)__popcll(__ballot(keep)); misses += (uint32_t)__popcll(__ballot(keep && pre_k < 0));
-                            if (keep) {
-                                int d0 = 0; V3 sample;
-                                SecTimer untimed;            // (diagnostic build: the staging phase is timed as a whole)
-                                KeyedUniformsT<kWidePhilox> UW; UW.k0 = a.k0; UW.k1 = a.k1;
-                                const bool done = shade_step<kLds, true>(gr, d0, pre_t, pre_k, gp, gs, a.max_depth, UW, s_geom, s_mat, s_aux, a.geom, a.mat, a.aux, nullptr, 0, sample, untimed);
-                                first = pre_k;
-                                if (done) {
-                                    float* o = a.samples + (size_t)gstore * 3;
-                                    o[0] = sample.x; o[1] = sample.y; o[2] = sample.z;
-                                    keep = false;
-                                }
-                            }
-                        }
-                    }
-                    T.mark(10);
-                    const unsigned long long km = __ballot(keep);
-                    const uint32_t slot = kept + __builtin_amdgcn_mbcnt_hi((uint32_t)(km >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)km, 0u));
-                    kept += (uint32_t)__popcll(km);
-                    if (keep) {
-                        float* rec = staged + (size_t)slot * kStagedFloats;
-                        v4f ra, rb, rc;
-                        ra.x = gr.o.x; ra.y = gr.o.y; ra.z = gr.o.z; ra.w = gr.d.x;
-                        rb.x = gr.d.y; rb.y = gr.d.z; rb.z = __uint_as_float(gp); rb.w = __uint_as_float(gs);
-                        rc.x = __uint_as_float(gstore); rc.y = __int_as_float(first); rc.z = 0.0f; rc.w = 0.0f;
-                        *reinterpret_cast<v4f*>(rec) = ra; *reinterpret_cast<v4f*>(rec + 4) = rb; *reinterpret_cast<v4f*>(rec + 8) = rc;
-                    }
-                }
+                const uint32_t kept = stage_chunk<kLds>(a, ig, g, claim_end, lane, fnx, fny, s_geom, s_mat, s_aux, staged, rays, misses, T);
                 pool_end = g + kept;        // what is handed out is the staged rows, not the items
                 T.mark(11);
                 // the rows are read back by other lanes of this wave: drain the stores first
@@ -503,7 +553,7 @@ __global__ void __launch_bounds__(trace_block(kMfma)) RT_TRACE_WAVES(kBvh, kLds)
             const uint32_t avail = pool_end - pool_next;
             const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(need >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)need, 0u));
             const uint32_t want = (uint32_t)__popcll(need);
-            if constexpr (kQueue) {
+            if constexpr (kQueue == 1) {
                 if (!active && rank < avail) {
                     const uint32_t row = pool_next + rank;
                     const v4f* rec = reinterpret_cast<const v4f*>(a.queue + (size_t)row * kQueueFloats);
@@ -534,7 +584,7 @@ __global__ void __launch_bounds__(trace_block(kMfma)) RT_TRACE_WAVES(kBvh, kLds)
             pool_next += (want < avail ? want : avail);
             need = __ballot(!active);
             // (a row of the queue can be empty -- a padding pixel -- so a lane may still be without a path here; it asks again)
-            if (want <= avail && !(kQueue && need != 0ull)) break;
+            if (want <= avail && !(kQueue == 1 && need != 0ull)) break;
         }
         T.mark(0);
         if (!__any(active)) {
@@ -669,11 +719,17 @@ namespace {
 using TraceKernel = void (*)(const TraceArgs);
 TraceKernel trace_kernel(const TracePlan& t)
 {
-    if (t.queue) {
-        if (t.mfma) return t.lds ? k_trace<true, true, false, true, true> : k_trace<false, true, false, true, true>;
-        if (t.bvh) return t.lds ? k_trace<true, true, true, false, true> : k_trace<false, true, true, false, true>;
-        if (t.lds) return t.plane ? k_trace<true, true, false, false, true> : k_trace<true, false, false, false, true>;
-        return t.plane ? k_trace<false, true, false, false, true> : k_trace<false, false, false, false, true>;
+    if (t.queue == 1) {
+        if (t.mfma) return t.lds ? k_trace<true, true, false, true, 1> : k_trace<false, true, false, true, 1>;
+        if (t.bvh) return t.lds ? k_trace<true, true, true, false, 1> : k_trace<false, true, true, false, 1>;
+        if (t.lds) return t.plane ? k_trace<true, true, false, false, 1> : k_trace<true, false, false, false, 1>;
+        return t.plane ? k_trace<false, true, false, false, 1> : k_trace<false, false, false, false, 1>;
+    }
+    if (t.queue == 2) {
+        if (t.mfma) return t.lds ? k_trace<true, true, false, true, 2> : k_trace<false, true, false, true, 2>;
+        if (t.bvh) return t.lds ? k_trace<true, true, true, false, 2> : k_trace<false, true, true, false, 2>;
+        if (t.lds) return t.plane ? k_trace<true, true, false, false, 2> : k_trace<true, false, false, false, 2>;
+        return t.plane ? k_trace<false, true, false, false, 2> : k_trace<false, false, false, false, 2>;
     }
     if (t.mfma) return t.lds ? k_trace<true, true, false, true> : k_trace<false, true, false, true>;
     if (t.bvh) return t.lds ? k_trace<true, true, true> : k_trace<false, true, true>;
@@ -738,7 +794,7 @@ int trace_prepare(rt_context* ctx, const RenderFrame& f, TracePlan* plan)
     // vector ALU -- the four spheres of the three-sphere test scene: 1.40 against 1.58 ms at 400x225x100)
     t.mfma = !t.bvh && t.plane && ctx->mfma_filter && ctx->n >= 20;
     t.block = trace_block(t.mfma);
-    t.queue = !ctx->primary_lists && ctx->primary_kernel;
+    t.queue = !ctx->primary_kernel ? 0 : ctx->primary_lists ? 2 : 1;
     // With the matrix-pipe filter a block keeps 40 + 16 bytes per sphere and 48 KB of mask words in LDS: two blocks per CU (six waves
     // per SIMD) up to 585 spheres, one above.  One block per CU loses more than LDS-resident records gain (600 spheres: 4.98 ms with
     // the records in LDS, 4.17 ms with them read from L2 at full occupancy; 1 536 spheres: 9.89 / 8.18 ms; tools/lds_threshold.py), so
@@ -746,7 +802,7 @@ int trace_prepare(rt_context* ctx, const RenderFrame& f, TracePlan* plan)
     if (t.mfma && t.lds && ctx->max_lds_spheres == 0 &&
         (size_t)ctx->n * kLdsBytesPerSphere + (size_t)((ctx->n + 31) / 32) * 512 + (size_t)(t.block / 64) * kSuperChunkWords * 64 * sizeof(uint32_t) + (size_t)t.block * sizeof(uint32_t) > 80u * 1024u) t.lds = false;
     t.shmem = (t.lds ? (size_t)ctx->n * kLdsBytesPerSphere + (t.mfma ? (size_t)((ctx->n + 31) / 32) * 512 : 0) : 0) + (size_t)(t.block / 64) * (t.bvh ? kBvhStack : kSuperChunkWords) * 64 * sizeof(uint32_t) + (t.mfma ? (size_t)t.block * sizeof(uint32_t) : 0);
-    int& bpc = ctx->trace_blocks_per_cu[(t.queue ? 8 : 0) + (t.mfma ? (t.lds ? 7 : 6) : t.bvh ? (t.lds ? 5 : 4) : (t.lds ? 1 : 0) + (t.plane ? 2 : 0))];
+    int& bpc = ctx->trace_blocks_per_cu[t.queue * 8 + (t.mfma ? (t.lds ? 7 : 6) : t.bvh ? (t.lds ? 5 : 4) : (t.lds ? 1 : 0) + (t.plane ? 2 : 0))];
     if (bpc == 0) {
         int nb = 0;
         hipError_t e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, trace_kernel(t), t.block, t.shmem);
@@ -765,7 +821,7 @@ int trace_prepare(rt_context* ctx, const RenderFrame& f, TracePlan* plan)
         ctx->stacks_lanes = lanes;
     }
     if (t.queue) {
-        const size_t need = (size_t)f.Q * (size_t)f.s_per * kQueueFloats * sizeof(float);
+        const size_t need = (size_t)f.Q * (size_t)f.s_per * (t.queue == 2 ? kStagedFloats : kQueueFloats) * sizeof(float);
         if (ctx->queue_bytes < need) {
             HIP_TRY(ctx, hipStreamSynchronize(st));
             (void)hipFree(ctx->d_queue); ctx->d_queue = nullptr; ctx->queue_bytes = 0;
@@ -813,6 +869,7 @@ int trace_batch(rt_context* ctx, const RenderFrame& f, const TracePlan& t, const
     a.tile_order = t.ordered ? ctx->d_tile_order : nullptr;
     a.tile_lists = ctx->primary_lists ? ctx->d_tile_lists : nullptr;
     a.queue = t.queue ? ctx->d_queue : nullptr;
+    a.seg_count = nullptr; a.n_segments = 0;
     a.bvh.nodes = ctx->d_bvh_nodes; a.bvh.leaf_index = ctx->d_bvh_leaf; a.bvh.big = ctx->d_bvh_big; a.bvh.n_big = ctx->bvh_n_big; a.bvh.geom = ctx->d_geom;
     // Chunk size.  A chunk costs its wave a fixed amount (the atomic, and the wave's live paths standing still while it stages the
     // chunk's camera rays), and what a wave still holds when the counter runs dry is proportional to the chunk: the sum is smallest
@@ -831,9 +888,20 @@ int trace_batch(rt_context* ctx, const RenderFrame& f, const TracePlan& t, const
     const uint64_t want_blocks = ((uint64_t)a.total_items + (uint64_t)a.chunk_items * (t.block / 64) - 1) / ((uint64_t)a.chunk_items * (t.block / 64));
     const uint64_t cap_blocks = (uint64_t)ctx->num_cu * t.blocks_per_cu;
     const dim3 grid((unsigned)(want_blocks < cap_blocks ? want_blocks : cap_blocks)), block(t.block);
-    // the first chunk of every launched wave is implied by its index; the counter hands out what follows
-    HIP_TRY(ctx, hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(ctx->d_work), (int)(grid.x * (unsigned)(t.block / 64) * (unsigned)a.chunk_items), 1, f.st));
-    if (t.queue) hipLaunchKernelGGL(k_primary, dim3((a.total_items + 255u) / 256u), dim3(256), 0, f.st, a);
+    // the first chunk (or segment) of every launched wave is implied by its index; the counter hands out what follows
+    HIP_TRY(ctx, hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(ctx->d_work), (int)(grid.x * (unsigned)(t.block / 64) * (t.queue == 2 ? 1u : (unsigned)a.chunk_items)), 1, f.st));
+    if (t.queue == 1) hipLaunchKernelGGL(k_primary, dim3((a.total_items + 255u) / 256u), dim3(256), 0, f.st, a);
+    if (t.queue == 2) {
+        a.n_segments = (a.total_items + (uint32_t)a.chunk_items - 1u) / (uint32_t)a.chunk_items;
+        if (ctx->seg_cap < a.n_segments) {
+            HIP_TRY(ctx, hipStreamSynchronize(f.st));
+            (void)hipFree(ctx->d_seg_count); ctx->d_seg_count = nullptr; ctx->seg_cap = 0;
+            HIP_TRY(ctx, hipMalloc(&ctx->d_seg_count, (size_t)a.n_segments * sizeof(uint32_t))); ctx->seg_cap = a.n_segments;
+        }
+        a.seg_count = ctx->d_seg_count;
+        const uint32_t lists_blocks = (a.n_segments + 3u) / 4u, lists_cap = (uint32_t)ctx->num_cu * 8u;
+        hipLaunchKernelGGL(k_primary_lists, dim3(lists_blocks < lists_cap ? lists_blocks : lists_cap), dim3(256), 0, f.st, a);
+    }
     hipLaunchKernelGGL(trace_kernel(t), grid, block, t.shmem, f.st, a);
     HIP_TRY(ctx, hipGetLastError());
     return RT_OK;
