@@ -2,6 +2,8 @@
 """Turns the rocprofv3 output of tools/profile_round.sh (gpurun_out/<tag>/) into the files kept under profiles/:
 <tag>_kernel_stats.csv (kernel-trace statistics of the default bench command), <tag>_pmc_k_trace.txt (raw counters of k_trace
 with the derived figures) and <tag>_pmc_k_trace.json (per-ray figures bench.py reads for roofline.traffic and executed_frac).
+The camera rays of a launch come from k_primary, which runs before k_trace: executed operations and HBM bytes per ray include it
+(its counters are listed apart), the cycle-based figures (issue share, wave time split, matrix pipe) are k_trace's.
 
 Units as observed on gfx950: SQ_*_CYCLES / SQ_ACTIVE_INST_* / SQ_WAIT_* count in units of four cycles summed over waves;
 SQ_INSTS_* count wave-instructions; FETCH_SIZE under-reports wide coalesced reads by a factor two (calibrated on k_resolve, whose
@@ -37,12 +39,16 @@ bench = json.load(open(os.path.join(src, "bench.json")))
 rays_per_sample = bench["rays_per_sample"]
 samples = 1200 * 800 * 50                      # the counter passes run the bench at 50 samples per pixel, one launch
 rays = samples * rays_per_sample
-c = {}
+c, cp = {}, {}
 for name in "abc":
     a, _ = counters(name)
     c.update(a)
+    a, _ = counters(name, "k_primary")
+    cp.update(a)
 fetch, _ = counters("fetch")
 write, _ = counters("write")
+pfetch, _ = counters("fetch", "k_primary")
+pwrite, _ = counters("write", "k_primary")
 rfetch, _ = counters("fetch", "k_resolve")
 shutil.copy(os.path.join(src, "bench.json"), os.path.join(dst, f"{tag}_bench_line.json"))
 
@@ -54,12 +60,16 @@ fma, add, mul, trans = (c.get(k, 0.0) for k in ("SQ_INSTS_VALU_FMA_F32", "SQ_INS
 # for), and scaled by the mean active-lane share of all vector instructions (the filter's FMAs run with every lane of a live
 # ray active, so the truth lies between)
 flop_wave = (2 * fma + add + mul + trans) * LANES
-executed_flop_per_ray_upper = flop_wave / rays
-executed_flop_per_ray_lanes = flop_wave * (lanes / LANES) / rays
-hbm_bytes = (2.0 * fetch.get("FETCH_SIZE", 0.0) + write.get("WRITE_SIZE", 0.0)) * 1024.0
+pflop_wave = (2 * cp.get("SQ_INSTS_VALU_FMA_F32", 0.0) + cp.get("SQ_INSTS_VALU_ADD_F32", 0.0) + cp.get("SQ_INSTS_VALU_MUL_F32", 0.0) + cp.get("SQ_INSTS_VALU_TRANS_F32", 0.0)) * LANES
+executed_flop_per_ray_upper = (flop_wave + pflop_wave) / rays
+executed_flop_per_ray_lanes = flop_wave * (lanes / LANES) / rays + pflop_wave / rays
+hbm_trace = (2.0 * fetch.get("FETCH_SIZE", 0.0) + write.get("WRITE_SIZE", 0.0)) * 1024.0
+hbm_primary = (2.0 * pfetch.get("FETCH_SIZE", 0.0) + pwrite.get("WRITE_SIZE", 0.0)) * 1024.0
+hbm_bytes = hbm_trace + hbm_primary
 summary = {
     "tag": tag, "workload": "1200x800 final scene, 50 spp (one launch of k_trace per counter pass)", "spheres": 487,
-    "rays": rays, "hbm_bytes_per_ray": hbm_bytes / rays,
+    "rays": rays, "hbm_bytes_per_ray": hbm_bytes / rays, "hbm_bytes_per_ray_k_trace": hbm_trace / rays, "hbm_bytes_per_ray_k_primary": hbm_primary / rays,
+    "k_primary_valu_insts_per_64_rays": cp.get("SQ_INSTS_VALU", 0.0) / (rays / 64),
     "valu_insts_per_64_rays": insts / (rays / 64), "mean_active_lanes": lanes,
     "fma_f32_per_64_rays": fma / (rays / 64), "add_f32_per_64_rays": add / (rays / 64), "mul_f32_per_64_rays": mul / (rays / 64),
     "trans_f32_per_64_rays": trans / (rays / 64), "int32_per_64_rays": c.get("SQ_INSTS_VALU_INT32", 0.0) / (rays / 64),
@@ -84,10 +94,15 @@ for name in ("default", "c3", "c1", "lists", "c5"):
     shutil.copy(st[0], os.path.join(dst, f"{tag}_kernel_stats_{name}.csv"))
     for r in csv.DictReader(open(st[0])):
         if "k_trace" in r["Name"]:
-            groups[name] = {"launches": int(r["Calls"]), "mean_ms": float(r["AverageNs"]) * 1e-6, "min_ms": float(r["MinNs"]) * 1e-6}
+            groups.setdefault(name, {}).update({"launches": int(r["Calls"]), "mean_ms": float(r["AverageNs"]) * 1e-6, "min_ms": float(r["MinNs"]) * 1e-6})
+        if r["Name"].startswith("k_primary"):
+            groups.setdefault(name, {}).update({"k_primary_mean_ms": float(r["AverageNs"]) * 1e-6})
+        if r["Name"].startswith("k_resolve"):
+            groups.setdefault(name, {}).update({"k_resolve_mean_ms": float(r["AverageNs"]) * 1e-6})
 summary["kernel_trace_groups"] = groups
 if "c3" in groups:
     summary["kernel_trace_headline_mean_ms"] = groups["c3"]["mean_ms"]
+    summary["kernel_trace_headline_step_ms"] = groups["c3"]["mean_ms"] + groups["c3"].get("k_primary_mean_ms", 0.0) + groups["c3"].get("k_resolve_mean_ms", 0.0)
 summary["bench_kernel_ms_mean"] = bench.get("kernel_ms_mean")
 with open(os.path.join(dst, f"{tag}_pmc_k_trace.txt"), "w") as f:
     f.write(f"# k_trace, bench.py --spp 50 --steps 1 (one launch per pass, {rays:.4g} rays); passes a, b, c of tools/profile_round.sh\n")
@@ -105,10 +120,15 @@ with open(os.path.join(dst, f"{tag}_pmc_k_trace.txt"), "w") as f:
     f.write(f"# wave time split: active {c['SQ_ACTIVE_INST_ANY'] / wc:.2f} issue-stall {c['SQ_WAIT_INST_ANY'] / wc:.2f} waitcnt {c['SQ_WAIT_ANY'] / wc:.2f}; waves {c['SQ_WAVES']:.0f}\n")
     f.write(f"# executed FP32 operations per ray: {executed_flop_per_ray_upper:.0f} with all 64 lanes counted, {executed_flop_per_ray_lanes:.0f} scaled by the active-lane share; "
             f"algorithmic (reference) work per ray: {18 * 487 + 150}\n")
-    f.write(f"# HBM bytes per ray: {summary['hbm_bytes_per_ray']:.1f} (FETCH_SIZE x 2 + WRITE_SIZE)\n")
+    f.write(f"# HBM bytes per ray: {summary['hbm_bytes_per_ray']:.1f} (FETCH_SIZE x 2 + WRITE_SIZE; k_trace {hbm_trace / rays:.1f}, k_primary {hbm_primary / rays:.1f})\n")
+    if cp:
+        f.write("# k_primary (camera rays of the launch, before k_trace): " + ", ".join(f"{k} {v:.0f}" for k, v in sorted(cp.items()) if k.startswith("SQ_INSTS") or k in ("SQ_WAVES", "GRBM_GUI_ACTIVE"))
+                + f"; FETCH_SIZE_KB {pfetch.get('FETCH_SIZE', 0):.0f} WRITE_SIZE_KB {pwrite.get('WRITE_SIZE', 0):.0f}\n")
     for name, g in groups.items():
-        f.write(f"# rocprofv3 --kernel-trace, command group {name}: {g['launches']} k_trace launches, mean {g['mean_ms']:.3f} ms, min {g['min_ms']:.3f} ms ({tag}_kernel_stats_{name}.csv)\n")
-    f.write(f"# bench.py's HIP-event figure for the headline (spans k_trace and k_resolve): {bench.get('kernel_ms_mean'):.2f} ms\n")
+        f.write(f"# rocprofv3 --kernel-trace, command group {name}: {g['launches']} k_trace launches, mean {g['mean_ms']:.3f} ms, min {g['min_ms']:.3f} ms"
+                + (f"; k_primary mean {g['k_primary_mean_ms']:.3f} ms" if "k_primary_mean_ms" in g else "") + (f"; k_resolve mean {g['k_resolve_mean_ms']:.3f} ms" if "k_resolve_mean_ms" in g else "")
+                + f" ({tag}_kernel_stats_{name}.csv)\n")
+    f.write(f"# bench.py's HIP-event figure for the headline (spans k_primary, k_trace and k_resolve): {bench.get('kernel_ms_mean'):.2f} ms\n")
     dpass, _ = counters("d")
     if dpass:
         trips = rays / 64
