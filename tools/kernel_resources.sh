@@ -29,9 +29,9 @@ for r in rows:
 PY
 done
 s=$tmp/rt_trace-hip-amdgcn-amd-amdhsa-gfx950.s
-awk '/^_Z7k_traceILb1ELb1ELb0ELb1EEv9TraceArgs:/,/s_endpgm/' $s > $tmp/kt.s
+awk '/^_Z7k_traceILb1ELb1ELb0ELb1ELi1EEv9TraceArgs:/,/s_endpgm/' $s > $tmp/kt.s
 first_atomic=$(grep -n "global_atomic_add " $tmp/kt.s | head -1 | cut -d: -f1)
-echo "# k_trace<lds, plane, no hierarchy, matrix-pipe filter> (the headline variant): $(wc -l < $tmp/kt.s) lines of ISA; the main loop's first hand-out atomic is at line ${first_atomic:-?}, everything before line ~400 is the prologue"
+echo "# k_trace<lds, plane, no hierarchy, matrix-pipe filter, rows from k_primary's queue> (the headline variant): $(wc -l < $tmp/kt.s) lines of ISA; the main loop's first hand-out atomic is at line ${first_atomic:-?}, everything before line ~400 is the prologue"
 echo "#   scratch stores at lines: $(grep -n scratch_store $tmp/kt.s | cut -d: -f1 | tr '\n' ' ')"
 echo "#   scratch loads: $(grep -c scratch_load $tmp/kt.s) (reloads of loop-invariant values; the stores all sit in the prologue when every line number above is below the hand-out atomic's)"
 echo "#   v_mfma instructions: $(grep -c v_mfma $tmp/kt.s), s_setprio: $(grep -c s_setprio $tmp/kt.s)"
