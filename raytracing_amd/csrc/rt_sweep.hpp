@@ -160,6 +160,9 @@ __device__ __forceinline__ uint32_t bf16_bits(float x)
     return (b + 0x7fffu + ((b >> 16) & 1u)) & 0xffff0000u;
 }
 
+#ifndef RT_PASSA_ADDR
+#define RT_PASSA_ADDR 1
+#endif
 template <bool kLds, bool kPlane, bool kPacked, bool kMfma = false>
 __device__ __forceinline__ void closest_hit(const RayD& ray, float tmin, const SweepScene& sw, const ExactLds& lds,
                                             uint32_t* mask_words, float& closest, int& hit, SecTimer& T, bool active = true, int prio_after = 0)
@@ -444,6 +447,14 @@ __device__ __forceinline__ void closest_hit(const RayD& ray, float tmin, const S
             nz &= ~(0x80000000u >> w);
             uint32_t cand = mask_words[w * 64], keep = 0u;
             int cbase = sbase + (w << 5);
+#if RT_PASSA_ADDR
+            // (LDS address of the word's first record, kept as a number the optimiser cannot fold back into the index: a survivor's
+            // address is then one shift-and-add)
+            typedef const __attribute__((address_space(3))) v4f* LdsRecord;
+            const uint32_t lds_geom = kLds ? (uint32_t)(uintptr_t)(LdsRecord)lds.geom : 0u;
+            uint32_t rec0 = lds_geom + ((uint32_t)cbase << 4);
+            asm volatile("" : "+v"(rec0));
+#endif
             for (;;) {
                 const int jj = __builtin_clz(cand);
                 const uint32_t bit = 0x80000000u >> jj;
@@ -451,8 +462,10 @@ __device__ __forceinline__ void closest_hit(const RayD& ray, float tmin, const S
                 const int k = cbase + jj;
                 // without the LDS mirror the discriminant-filter record itself is gathered: it holds the same centre as the exact
                 // record and the constant beside it (one 16-byte load per survivor instead of two)
-#ifdef RT_PASSA_ADDR
-                const float4 g = kLds ? *reinterpret_cast<const float4*>(reinterpret_cast<const char*>(lds.geom) + (((uint32_t)cbase << 4) + ((uint32_t)jj << 4))) : sw.frec[k];
+#if RT_PASSA_ADDR
+                float4 g;
+                if constexpr (kLds) { const v4f q = *(LdsRecord)(uintptr_t)(((uint32_t)jj << 4) + rec0); g = make_float4(q.x, q.y, q.z, q.w); }
+                else g = sw.frec[k];
 #else
                 const float4 g = kLds ? lds.geom[k] : sw.frec[k];
 #endif
@@ -472,6 +485,10 @@ __device__ __forceinline__ void closest_hit(const RayD& ray, float tmin, const S
                     cand = mask_words[w * 64];
                     keep = 0u;
                     cbase = sbase + (w << 5);
+#if RT_PASSA_ADDR
+                    rec0 = lds_geom + ((uint32_t)cbase << 4);
+                    asm volatile("" : "+v"(rec0));
+#endif
                 }
             }
         }
