@@ -60,7 +60,7 @@ struct BvhScene {
 #ifdef RT_WAVE_TIMELINE
 // Diagnostic build (-DRT_WAVE_TIMELINE), per wave of the last k_trace launch: s_memrealtime (100 MHz, common to all XCDs) at entry, when the wave first found the work counter dry, at exit;
 // and how many trips of the main loop it made after that point
-static __device__ unsigned long long g_wave_times[8][8192];      // rows 4, 5: trips made with the sparse sweep, ticks spent in those trips (whole trip); 6: first sweep starts; 7: first trip ends
+static __device__ unsigned long long g_wave_times[10][8192];     // rows 4, 5: trips made with the sparse sweep, ticks spent in those trips (whole trip); 6: first sweep starts; 7: first trip ends; 8: the block's shared end begins (0: never); 9: its bounces
 #endif
 #ifdef RT_SECTION_TIMERS
 static constexpr int kSections = 12;
@@ -542,6 +542,14 @@ __device__ __forceinline__ void closest_hit(const RayD& ray, float tmin, const S
 #define RT_PRIO_2 16
 #define RT_PRIO_3 32
 #endif
+// The end of a launch shared by a block (k_trace, matrix-pipe variants): its waves pool their last paths once they hold no more than
+// this many together (0: every wave drains its own)
+#ifndef RT_TAIL_PATHS
+#define RT_TAIL_PATHS 48
+#endif
+constexpr int kTailPaths = RT_TAIL_PATHS;
+constexpr int kTailCtlBytes = 128;          // control words of the shared end, at the start of the block's LDS
+constexpr int kTailFields = 10;             // words per pooled path: origin, direction, pixel key, sample, depth | stack owner << 8, sample-buffer slot
 constexpr int kFewPaths = RT_FEW_PATHS;     // 2, 4 and 8 measure alike on the 1200x800 final scene at 10 spp, 16 and 24 are 4-6 % slower (tools/ab_few.sh)
 template <bool kLds>
 __device__ __forceinline__ void closest_hit_few(const RayD& ray, float tmin, const SweepScene& sw, const ExactLds& lds,
@@ -712,13 +720,24 @@ __device__ __forceinline__ void closest_hit_bvh(const RayD& ray, float tmin, con
 // ============================================================================ shading step of Color()
 // One level of the recursion main.cpp:13-39 for a ray whose closest hit is known.  Returns true when the
 // path has ended (sample = its radiance); otherwise ray/depth are advanced and the hit index is pushed on
-// the lane's stack (element k at stack[k * sstride]).
+// the lane's stack (stack.at(depth)).
 // kNoStack: for a camera ray (depth 0) whose caller records the hit index itself; nothing is pushed and there is nothing to replay.
-template <bool kLds, bool kNoStack = false, class Uniforms = KeyedUniforms>
+// The hit-index stack of a path, two forms: a per-lane pointer with a stride between levels, and -- for the persistent kernel,
+// where a 64-bit pointer per lane is two registers held across the whole main loop -- a base every lane shares plus the lane's
+// 32-bit column (level k of column c at base[k * stride + c]; the address is then a scalar base and one 32-bit vector offset).
+struct StridedStack {
+    uint16_t* p; size_t stride;
+    __device__ __forceinline__ uint16_t& at(int k) const { return p[(size_t)k * stride]; }
+};
+struct ColumnStack {
+    uint16_t* base; uint32_t column, stride;        // stride * RT_MAX_DEPTH + column < 2^31: the byte offset is formed in 32 bits
+    __device__ __forceinline__ uint16_t& at(int k) const { return *reinterpret_cast<uint16_t*>(reinterpret_cast<char*>(base) + (((uint32_t)k * stride + column) << 1)); }
+};
+template <bool kLds, bool kNoStack = false, class Uniforms = KeyedUniforms, class Stack = StridedStack>
 __device__ __forceinline__ bool shade_step(RayD& ray, int& depth, float closest, int hit, uint32_t pix, uint32_t smp, int max_depth,
                                            Uniforms& U, const float4* s_geom, const float4* s_mat, const Aux* s_aux,
                                            const float4* g_geom, const float4* g_mat, const Aux* g_aux,
-                                           uint16_t* stack, size_t sstride, V3& sample, SecTimer& T)
+                                           const Stack& stack, V3& sample, SecTimer& T)
 {
     sample = mk(0.0f, 0.0f, 0.0f);
     bool done = true;
@@ -733,7 +752,7 @@ __device__ __forceinline__ bool shade_step(RayD& ray, int& depth, float closest,
             V3 att; RayD out;
             U.slot(pix, smp, (uint32_t)depth + 1u);
             if (scatter(x.type, mk(m.x, m.y, m.z), m.w, ray, p, nrm, U, att, out)) {
-                if (!kNoStack) stack[(size_t)depth * sstride] = (uint16_t)hit;
+                if (!kNoStack) stack.at(depth) = (uint16_t)hit;
                 ++depth; ray = out; done = false;
             }
         }
@@ -741,7 +760,7 @@ __device__ __forceinline__ bool shade_step(RayD& ray, int& depth, float closest,
     } else {
         sample = sky(ray.d);
         for (int k = kNoStack ? -1 : depth - 1; k >= 0; --k) {
-            const int h = stack[(size_t)k * sstride];
+            const int h = stack.at(k);
             const float4 m = kLds ? s_mat[h] : g_mat[h];
             sample = mk(m.x, m.y, m.z) * sample;
         }

@@ -369,7 +369,7 @@ __device__ __forceinline__ uint32_t stage_chunk(const TraceArgs& a, const ItemGe
                     int d0 = 0; V3 sample;
                     SecTimer untimed;            // (diagnostic build: the staging phase is timed as a whole)
                     KeyedUniformsT<kWidePhilox> UW; UW.k0 = a.k0; UW.k1 = a.k1;
-                    const bool done = shade_step<kLds, true>(gr, d0, pre_t, pre_k, gp, gs, a.max_depth, UW, s_geom, s_mat, s_aux, a.geom, a.mat, a.aux, nullptr, 0, sample, untimed);
+                    const bool done = shade_step<kLds, true>(gr, d0, pre_t, pre_k, gp, gs, a.max_depth, UW, s_geom, s_mat, s_aux, a.geom, a.mat, a.aux, StridedStack{ nullptr, 0 }, sample, untimed);
                     first = pre_k;
                     if (done) {
                         float* o = a.samples + (size_t)gstore * 3;
@@ -418,6 +418,12 @@ __global__ void __launch_bounds__(256) k_primary_lists(const TraceArgs a)
     if (lane == 0 && rays) { atomicAdd(a.ray_counter, (unsigned long long)rays); atomicAdd(a.ray_counter + 1, (unsigned long long)misses); }
 }
 
+// A word of LDS that other waves of the block change, read afresh (a plain LDS load, not one through the generic address space)
+__device__ __forceinline__ uint32_t lds_word_now(const uint32_t* p)
+{
+    typedef volatile __attribute__((address_space(3))) uint32_t LdsWord;
+    return *(LdsWord*)p;
+}
 template <bool kLds, bool kPlane, bool kBvh = false, bool kMfma = false, int kQueue = 0>
 __global__ void __launch_bounds__(trace_block(kMfma)) RT_TRACE_WAVES(kBvh, kLds) k_trace(const TraceArgs a)
 {
@@ -430,11 +436,18 @@ __global__ void __launch_bounds__(trace_block(kMfma)) RT_TRACE_WAVES(kBvh, kLds)
     // LDS: [geom n][mat n][aux n (8 B)] when kLds; geom in the packed form of ExactLds (centre, discriminant-filter constant)
     // for the sweep, in the plain form (centre, r*r) for the hierarchy walk.  With the matrix-pipe filter its A operands follow
     // (512 bytes per chunk of 32 spheres).
-    float4* s_geom = smem;
-    float4* s_mat = smem + (kLds ? a.n : 0);
-    Aux* s_aux = reinterpret_cast<Aux*>(smem + (kLds ? 2 * a.n : 0));
+    // The end of a launch is shared by the block in the matrix-pipe variants ("the last paths of a block" in the main loop).  Its
+    // control words come first, at addresses known when the kernel is compiled (no register holds them): [0] = (waves of this block
+    // that can get no more items) << 16 | paths those waves hold, [1..3] = number of entries of the three rotating path tables,
+    // [4 + w] = paths wave w has announced, [16 + w] = which bounce of the shared end wave w is in (kTailIdle: not in it).
+    constexpr bool kTail = kMfma && !kBvh && kTailPaths > 0;
+    uint32_t* tail_ctl = reinterpret_cast<uint32_t*>(smem);
+    float4* scene_lds = smem + (kTail ? kTailCtlBytes / 16 : 0);
+    float4* s_geom = scene_lds;
+    float4* s_mat = scene_lds + (kLds ? a.n : 0);
+    Aux* s_aux = reinterpret_cast<Aux*>(scene_lds + (kLds ? 2 * a.n : 0));
     const int a_words = kLds && kMfma ? ((a.n + 31) >> 5) * 64 : 0;       // uint2 entries
-    uint2* s_arec = reinterpret_cast<uint2*>(reinterpret_cast<char*>(smem) + (kLds ? (size_t)a.n * kLdsBytesPerSphere : 0));
+    uint2* s_arec = reinterpret_cast<uint2*>(reinterpret_cast<char*>(scene_lds) + (kLds ? (size_t)a.n * kLdsBytesPerSphere : 0));
     if (kLds) {
         for (int i = threadIdx.x; i < a.n; i += kTraceBlock) { const float4 g = a.geom[i]; s_geom[i] = make_float4(g.x, g.y, g.z, kBvh ? g.w : a.frec[i].w); s_mat[i] = a.mat[i]; s_aux[i] = a.aux[i]; }
         for (int i = threadIdx.x; i < a_words; i += kTraceBlock) s_arec[i] = a.arec[i];
@@ -442,22 +455,35 @@ __global__ void __launch_bounds__(trace_block(kMfma)) RT_TRACE_WAVES(kBvh, kLds)
     ExactLds exact_lds{ s_geom, s_aux, nullptr }; exact_lds.arec = s_arec;
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     // Per-lane filter masks of one super-chunk: word w of lane l at mask_words[w * 64] (lanes contiguous).
-    char* lds_after_scene = reinterpret_cast<char*>(smem) + (kLds ? (size_t)a.n * kLdsBytesPerSphere : 0) + (size_t)a_words * sizeof(uint2);
+    char* lds_after_scene = reinterpret_cast<char*>(scene_lds) + (kLds ? (size_t)a.n * kLdsBytesPerSphere : 0) + (size_t)a_words * sizeof(uint2);
     // (In RT_MODE_BVH the same area holds each lane's stack of pending nodes instead.)
     constexpr int kWordsPerLane = kBvh ? kBvhStack : kSuperChunkWords;
-    uint32_t* mask_words = reinterpret_cast<uint32_t*>(lds_after_scene) + (size_t)wave * kWordsPerLane * 64 + lane;
+    // (with the item slots below, a wave's area is kWordsPerLane + 1 words per lane)
+    uint32_t* mask_words = reinterpret_cast<uint32_t*>(lds_after_scene) + (size_t)wave * (kWordsPerLane + (kMfma ? 1 : 0)) * 64 + lane;
     // One more LDS word per lane behind the mask words (matrix-pipe variant: 3 KB per block, what is left under two blocks per CU):
     // the sample-buffer slot of the lane's path, written when the lane takes an item and read once when its path ends.  In a
     // register it was one of a dozen values the allocator kept in scratch memory, and every scratch store of the main loop went
     // out to HBM (18 of 48 bytes written per ray).
-    uint32_t* item_slot = reinterpret_cast<uint32_t*>(lds_after_scene) + (size_t)(kTraceBlock / 64) * kWordsPerLane * 64 + threadIdx.x;
+    // It sits right behind the wave's mask words, so that one address register serves both.
+    uint32_t* item_slot = mask_words + kWordsPerLane * 64;
+    uint32_t* tail_table = reinterpret_cast<uint32_t*>(lds_after_scene);       // [2 tables][kTailFields][kTailPaths], in the words of the filter masks
+    constexpr uint32_t kTailIdle = 0xffffffffu;
+    static_assert(!kTail || 16 + kTraceBlock / 64 <= kTailCtlBytes / 4, "control words of the shared end");
+    // Whose hit-index stack the lane's path uses, during the shared end: only the first few lanes of a wave hold a path then, and
+    // lane l keeps the number in the item slot of lane l + 32 (an address offset, no register)
+    static_assert(!kTail || (kTailPaths + kTraceBlock / 64 - 1) / (kTraceBlock / 64) <= 32, "a wave's share of the pooled paths must fit its first 32 lanes");
+    static_assert(!kTail || kTailPaths <= kFewPaths * (kTraceBlock / 64), "a wave's share of the pooled paths must stay with the sparse sweep: the tables lie in the mask words");
+    static_assert(!kTail || 2 * kTailFields * kTailPaths <= kSuperChunkWords * 64, "both path tables lie in the mask words of the block's first wave");
+    uint32_t* stack_owner = item_slot + 32;
+    if (kTail && threadIdx.x < kTailCtlBytes / 4) tail_ctl[threadIdx.x] = threadIdx.x < 4 ? 0u : kTailIdle;
     __syncthreads();
     // The recursion's attenuation chain is replayed innermost-first when a path reaches the sky, so
     // each lane keeps the indices of the spheres it bounced off.  One 2-byte store per bounce and a
     // short read-back per finished path: kept in HBM so that LDS does not limit occupancy (packing the
     // first levels into registers was measured 1.5 % slower: the loads are hidden by the other waves).
-    uint16_t* stack = a.stacks + (size_t)blockIdx.x * kTraceBlock + threadIdx.x;
-    const size_t sstride = a.stack_stride;
+    // The stack of a lane is a column of a.stacks: level k of this thread at block_stacks[k * stack_stride + threadIdx.x] (a base the
+    // block shares and the thread's number, which is in a register anyway: no per-lane pointer is held across the main loop).
+    uint16_t* const block_stacks = a.stacks + (size_t)blockIdx.x * kTraceBlock;
 
     // Philox products in the shading of the main loop: one 64-bit multiply per product (half the multiplier work) where the
     // register allocation has room for the pairs -- with the matrix-pipe filter it has (config 3: 76.4 -> 74.9 ms); in the other
@@ -482,7 +508,7 @@ __global__ void __launch_bounds__(trace_block(kMfma)) RT_TRACE_WAVES(kBvh, kLds)
     SweepScene sw; sw.arec = a.arec; sw.mfma_g = a.mfma_g; sw.frec = a.frec; sw.prec = a.prec; sw.force = a.force; sw.n_forced = a.n_forced; sw.plane_s0 = a.plane_s0; sw.plane_rmin = a.plane_rmin; sw.geom = a.geom; sw.n = a.n; sw.n_pad = a.n_pad;
 
 #ifdef RT_WAVE_TIMELINE
-    const unsigned long long t_enter = __builtin_amdgcn_s_memrealtime(); unsigned long long t_dry = 0, trips_dry = 0, sparse_trips = 0, sparse_ticks = 0, t_trip = 0, t_first_sweep = 0, t_first_done = 0; bool was_sparse = false;
+    const unsigned long long t_enter = __builtin_amdgcn_s_memrealtime(); unsigned long long t_dry = 0, trips_dry = 0, sparse_trips = 0, sparse_ticks = 0, t_trip = 0, t_first_sweep = 0, t_first_done = 0, t_shared = 0, shared_bounces = 0; bool was_sparse = false;
 #endif
     for (;;) {
 #ifdef RT_WAVE_TIMELINE
@@ -578,7 +604,7 @@ __global__ void __launch_bounds__(trace_block(kMfma)) RT_TRACE_WAVES(kBvh, kLds)
                 // a staged second ray comes with the sphere its path left: the first entry of this lane's hit stack
                 const int first = __float_as_int(rc.y);
                 depth = 0;
-                if (first != kUnresolved) { stack[0] = (uint16_t)first; depth = 1; }
+                if (first != kUnresolved) { block_stacks[threadIdx.x] = (uint16_t)first; depth = 1; }
                 active = true;
             }
             pool_next += (want < avail ? want : avail);
@@ -587,7 +613,93 @@ __global__ void __launch_bounds__(trace_block(kMfma)) RT_TRACE_WAVES(kBvh, kLds)
             if (want <= avail && !(kQueue == 1 && need != 0ull)) break;
         }
         T.mark(0);
+        // ---------------------------------------------------------------- the last paths of a block
+        // When the work counter has run dry a wave drains the paths it holds: one with 20 paths left makes ordinary trips for
+        // them while its eleven neighbours, done or nearly done, cannot help, and the launch ends when the last such wave does.
+        // Instead the block's waves pool what they hold and deal it out afresh before every bounce: path s of the table goes to
+        // wave s mod 12, which sweeps its few paths with the spheres spread over the lanes (closest_hit_few), shades them and
+        // appends the ones that go on to the next table; one barrier per bounce.  A path keeps the hit-index stack of the thread
+        // it started on (the stack stays where it is, in HBM; the path carries that thread's number).  Nothing about a path's
+        // arithmetic changes: same rays, same draws, same order of products.
+        uint32_t tail_bounce = kTailIdle;          // wave-uniform: the bounce of the block's shared end this trip is (not in it)
+        if constexpr (kTail) {
+            // (Everything here sits behind "this wave can get no more items" -- a flag the hand-out keeps anyway -- and the state of
+            // the shared end lives in LDS, so the trips of a long launch carry no register for it.)
+            if (exhausted && pool_next == pool_end) {
+                // the wave's number as a scalar, formed here (as a per-lane value it is hoisted out of the main loop and costs a register there)
+                uint32_t* mine = tail_ctl + __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+                tail_bounce = (uint32_t)__builtin_amdgcn_readfirstlane((int)lds_word_now(mine + 16));
+                if (tail_bounce == kTailIdle) {
+                    // This wave says once that it is out of items, keeps the number of paths it still holds up to date, and goes
+                    // to the block's barrier when it holds none, or when every wave of the block is out of items and together they
+                    // hold at most kTailPaths paths.  Both numbers live in one word (a wave's paths are added with its
+                    // announcement, so whoever sees all waves announced sees all their paths); once all have announced the word
+                    // only falls, so every wave that tests it later decides the same way, and every wave of the block arrives at
+                    // the first barrier exactly once.  Behind it no wave is in a sweep any more: the mask words are free for the tables.
+                    const uint32_t nlive = (uint32_t)__popcll(__ballot(active));
+                    if (lane == 0) {
+                        const uint32_t published = mine[4];
+                        if (published == kTailIdle) atomicAdd(tail_ctl, 0x10000u + nlive);
+                        else if (nlive != published) atomicSub(tail_ctl, published - nlive);
+                        mine[4] = nlive;
+                    }
+                    bool go = nlive == 0u;
+                    if (!go) {
+                        const uint32_t word = (uint32_t)__builtin_amdgcn_readfirstlane((int)lds_word_now(tail_ctl));
+                        go = (word >> 16) == (uint32_t)(kTraceBlock / 64) && (word & 0xffffu) <= (uint32_t)kTailPaths;
+                    }
+                    if (go) {
+                        __syncthreads();
+                        const unsigned long long lm = __ballot(active);
+                        uint32_t base = 0u;
+                        if (lm != 0ull) {
+                            if (lane == 0) base = atomicAdd(&tail_ctl[1], (uint32_t)__popcll(lm));
+                            base = (uint32_t)__builtin_amdgcn_readfirstlane((int)base);
+                        }
+                        if (active) {
+                            uint32_t* e = tail_table + base + __builtin_amdgcn_mbcnt_hi((uint32_t)(lm >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)lm, 0u));
+                            e[0 * kTailPaths] = __float_as_uint(ray.o.x); e[1 * kTailPaths] = __float_as_uint(ray.o.y); e[2 * kTailPaths] = __float_as_uint(ray.o.z);
+                            e[3 * kTailPaths] = __float_as_uint(ray.d.x); e[4 * kTailPaths] = __float_as_uint(ray.d.y); e[5 * kTailPaths] = __float_as_uint(ray.d.z);
+                            e[6 * kTailPaths] = pix; e[7 * kTailPaths] = smp; e[8 * kTailPaths] = (uint32_t)depth | (threadIdx.x << 8);
+                            e[9 * kTailPaths] = kItemInLds ? *item_slot : item;
+                        }
+                        active = false;
+                        if (lane == 0) mine[16] = 0u;
+                        __syncthreads();
+                        tail_bounce = 0u;
+#ifdef RT_WAVE_TIMELINE
+                        t_shared = __builtin_amdgcn_s_memrealtime();
+#endif
+                    }
+                }
+                if (tail_bounce != kTailIdle) {
+                    // bounce b reads table b % 2, whose entry count is word 1 + b % 3; all waves of the block read the same count
+                    // after the same barrier, so they leave together
+                    const uint32_t c_cur = tail_bounce % 3u;
+                    const uint32_t n = (uint32_t)__builtin_amdgcn_readfirstlane((int)lds_word_now(&tail_ctl[1u + c_cur]));
+                    if (n == 0u) break;
+#ifdef RT_WAVE_TIMELINE
+                    ++shared_bounces;
+#endif
+                    if (threadIdx.x == 0) tail_ctl[1u + (c_cur + 2u) % 3u] = 0u;          // read two bounces ago, appended to in the next one
+                    const uint32_t* src = tail_table + (tail_bounce & 1u) * (uint32_t)(kTailFields * kTailPaths);
+                    const uint32_t slot = (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)) + (uint32_t)(kTraceBlock / 64) * (uint32_t)lane;
+                    if (slot < n) {
+                        ray.o = mk(__uint_as_float(src[0 * kTailPaths + slot]), __uint_as_float(src[1 * kTailPaths + slot]), __uint_as_float(src[2 * kTailPaths + slot]));
+                        ray.d = mk(__uint_as_float(src[3 * kTailPaths + slot]), __uint_as_float(src[4 * kTailPaths + slot]), __uint_as_float(src[5 * kTailPaths + slot]));
+                        pix = src[6 * kTailPaths + slot]; smp = src[7 * kTailPaths + slot];
+                        const uint32_t dw = src[8 * kTailPaths + slot];
+                        depth = (int)(dw & 0xffu);
+                        *stack_owner = dw >> 8;
+                        if (kItemInLds) *item_slot = src[9 * kTailPaths + slot]; else item = src[9 * kTailPaths + slot];
+                        active = true;
+                    }
+                    if (lane == 0) mine[16] = tail_bounce + 1u;          // (this wave's own word: read at the top of its next trip)
+                }
+            }
+        }
         if (!__any(active)) {
+            if (kTail && tail_bounce != kTailIdle) { __syncthreads(); continue; }
             if (exhausted && pool_next == pool_end) break;
             continue;
         }
@@ -620,7 +732,14 @@ __global__ void __launch_bounds__(trace_block(kMfma)) RT_TRACE_WAVES(kBvh, kLds)
             T.mark(4);
             // ------------------------------------------------------------ shade (main.cpp:13-39)
             V3 sample;
-            const bool done = shade_step<kLds>(ray, depth, closest, hit, pix, smp, a.max_depth, U, s_geom, s_mat, s_aux, a.geom, a.mat, a.aux, stack, sstride, sample, T);
+            ColumnStack path_stack{ block_stacks, threadIdx.x, a.stack_stride };
+            if constexpr (kTail) {
+                // (asked of the wave's own word again rather than carried across the sweep; it holds the next bounce by now)
+                if (exhausted && pool_next == pool_end &&
+                    lds_word_now(tail_ctl + 16 + __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6))) != kTailIdle)
+                    path_stack.column = *stack_owner;
+            }
+            const bool done = shade_step<kLds>(ray, depth, closest, hit, pix, smp, a.max_depth, U, s_geom, s_mat, s_aux, a.geom, a.mat, a.aux, path_stack, sample, T);
             if (done) {
                 float* o = a.samples + (size_t)(kItemInLds ? *item_slot : item) * 3;
                 o[0] = sample.x; o[1] = sample.y; o[2] = sample.z;
@@ -628,12 +747,37 @@ __global__ void __launch_bounds__(trace_block(kMfma)) RT_TRACE_WAVES(kBvh, kLds)
             }
             T.mark(7);
         }
+        if constexpr (kTail) {
+            if (exhausted && pool_next == pool_end) {
+                // (the bounce this trip was is one less than what the wave's word says now)
+                const uint32_t next_bounce = (uint32_t)__builtin_amdgcn_readfirstlane((int)lds_word_now(tail_ctl + 16 + __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6))));
+                if (next_bounce != kTailIdle) {
+                    // the paths that go on: into the other table, behind what the other waves have put there
+                    const unsigned long long gm = __ballot(active);
+                    if (gm != 0ull) {
+                        uint32_t base = 0u;
+                        if (lane == 0) base = atomicAdd(&tail_ctl[1u + next_bounce % 3u], (uint32_t)__popcll(gm));
+                        base = (uint32_t)__builtin_amdgcn_readfirstlane((int)base);
+                        if (active) {
+                            uint32_t* e = tail_table + (next_bounce & 1u) * (uint32_t)(kTailFields * kTailPaths) + base + __builtin_amdgcn_mbcnt_hi((uint32_t)(gm >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)gm, 0u));
+                            e[0 * kTailPaths] = __float_as_uint(ray.o.x); e[1 * kTailPaths] = __float_as_uint(ray.o.y); e[2 * kTailPaths] = __float_as_uint(ray.o.z);
+                            e[3 * kTailPaths] = __float_as_uint(ray.d.x); e[4 * kTailPaths] = __float_as_uint(ray.d.y); e[5 * kTailPaths] = __float_as_uint(ray.d.z);
+                            e[6 * kTailPaths] = pix; e[7 * kTailPaths] = smp;
+                            e[8 * kTailPaths] = (uint32_t)depth | (*stack_owner << 8);
+                            e[9 * kTailPaths] = kItemInLds ? *item_slot : item;
+                        }
+                        active = false;
+                    }
+                    __syncthreads();
+                }
+            }
+        }
     }
     T.flush(lane);
 #ifdef RT_WAVE_TIMELINE
     {
         const uint32_t w = blockIdx.x * (kTraceBlock / 64) + wave;
-        if (lane == 0 && w < 8192u) { g_wave_times[0][w] = t_enter; const unsigned long long t_exit = __builtin_amdgcn_s_memrealtime(); g_wave_times[1][w] = t_dry ? t_dry : t_exit; g_wave_times[2][w] = t_exit; g_wave_times[3][w] = trips_dry; g_wave_times[4][w] = sparse_trips; g_wave_times[5][w] = sparse_ticks; g_wave_times[6][w] = t_first_sweep; g_wave_times[7][w] = t_first_done; }
+        if (lane == 0 && w < 8192u) { g_wave_times[0][w] = t_enter; const unsigned long long t_exit = __builtin_amdgcn_s_memrealtime(); g_wave_times[1][w] = t_dry ? t_dry : t_exit; g_wave_times[2][w] = t_exit; g_wave_times[3][w] = trips_dry; g_wave_times[4][w] = sparse_trips; g_wave_times[5][w] = sparse_ticks; g_wave_times[6][w] = t_first_sweep; g_wave_times[7][w] = t_first_done; g_wave_times[8][w] = t_shared; g_wave_times[9][w] = shared_bounces; }
     }
 #endif
     // one atomic per wave
@@ -709,9 +853,9 @@ extern "C" int rt_debug_section_ticks(unsigned long long* out8, int reset)   /* 
 }
 #endif
 #ifdef RT_WAVE_TIMELINE
-extern "C" int rt_debug_wave_times(unsigned long long* out_6x8192)   /* 8 rows of 8192 */
+extern "C" int rt_debug_wave_times(unsigned long long* out_6x8192)   /* 10 rows of 8192 */
 {
-    return hipMemcpyFromSymbol(out_6x8192, HIP_SYMBOL(g_wave_times), 8 * 8192 * sizeof(unsigned long long)) == hipSuccess ? 0 : -3;
+    return hipMemcpyFromSymbol(out_6x8192, HIP_SYMBOL(g_wave_times), 10 * 8192 * sizeof(unsigned long long)) == hipSuccess ? 0 : -3;
 }
 #endif
 
@@ -800,8 +944,8 @@ int trace_prepare(rt_context* ctx, const RenderFrame& f, TracePlan* plan)
     // the records in LDS, 4.17 ms with them read from L2 at full occupancy; 1 536 spheres: 9.89 / 8.18 ms; tools/lds_threshold.py), so
     // the records stay in LDS only while two blocks fit.
     if (t.mfma && t.lds && ctx->max_lds_spheres == 0 &&
-        (size_t)ctx->n * kLdsBytesPerSphere + (size_t)((ctx->n + 31) / 32) * 512 + (size_t)(t.block / 64) * kSuperChunkWords * 64 * sizeof(uint32_t) + (size_t)t.block * sizeof(uint32_t) > 80u * 1024u) t.lds = false;
-    t.shmem = (t.lds ? (size_t)ctx->n * kLdsBytesPerSphere + (t.mfma ? (size_t)((ctx->n + 31) / 32) * 512 : 0) : 0) + (size_t)(t.block / 64) * (t.bvh ? kBvhStack : kSuperChunkWords) * 64 * sizeof(uint32_t) + (t.mfma ? (size_t)t.block * sizeof(uint32_t) : 0);
+        (size_t)ctx->n * kLdsBytesPerSphere + (size_t)((ctx->n + 31) / 32) * 512 + (size_t)(t.block / 64) * kSuperChunkWords * 64 * sizeof(uint32_t) + (size_t)t.block * sizeof(uint32_t) + (kTailPaths > 0 ? kTailCtlBytes : 0) > 80u * 1024u) t.lds = false;
+    t.shmem = (t.lds ? (size_t)ctx->n * kLdsBytesPerSphere + (t.mfma ? (size_t)((ctx->n + 31) / 32) * 512 : 0) : 0) + (size_t)(t.block / 64) * (t.bvh ? kBvhStack : kSuperChunkWords) * 64 * sizeof(uint32_t) + (t.mfma ? (size_t)t.block * sizeof(uint32_t) + (kTailPaths > 0 ? kTailCtlBytes : 0) : 0);
     int& bpc = ctx->trace_blocks_per_cu[t.queue * 8 + (t.mfma ? (t.lds ? 7 : 6) : t.bvh ? (t.lds ? 5 : 4) : (t.lds ? 1 : 0) + (t.plane ? 2 : 0))];
     if (bpc == 0) {
         int nb = 0;

@@ -113,7 +113,7 @@ __global__ void __launch_bounds__(kWfShadeBlock) k_wf_shade(const WfArgs a)
         if (pix != 0xffffffffu) {
             traced = true; missed = a.hit_idx[s] < 0;
             done = shade_step<false>(ray, depth, a.hit_t[s], a.hit_idx[s], pix, smp, a.max_depth, U, nullptr, nullptr, nullptr,
-                                     a.sw.geom, a.mat, a.aux, a.stacks + s, (size_t)a.P, sample, T);
+                                     a.sw.geom, a.mat, a.aux, StridedStack{ a.stacks + s, (size_t)a.P }, sample, T);
             if (done) { float* o = a.samples + (size_t)item * 3; o[0] = sample.x; o[1] = sample.y; o[2] = sample.z; }
         }
         need = done;

@@ -493,6 +493,59 @@ def test_random_scenes_match_oracle_in_all_modes(rt):
             assert np.array_equal(irgb, wq), (case, n, mode)
 
 
+def test_last_paths_of_a_launch_are_shared_by_the_block(rt):
+    """The end of a launch: once the work counter is dry the waves of a block pool the paths they still hold and deal them out
+    afresh before every bounce (a path then runs on other threads than the one it started on, with that thread's hit-index
+    stack).  A closed mirror shell (negative radius: the normal points inwards, Metal::Scatter never absorbs, material.h:73-91)
+    around camera and spheres keeps every path alive to the depth cap, so launches of a few paths spend nearly all their
+    bounces in that phase; images, integers, ray count and counters against the oracle, and larger ones against the
+    one-lane-per-pixel kernel."""
+    rng = np.random.default_rng(77)
+    n = 40
+    t = np.zeros((n, 9), dtype=np.float64)
+    t[0] = [0.0, 0.0, 0.0, -30.0, R.METAL, 0.97, 0.95, 0.9, 0.0]
+    t[1:, 0:3] = rng.uniform(-6.0, 6.0, size=(n - 1, 3))
+    t[1:, 3] = rng.uniform(0.3, 1.2, size=n - 1)
+    t[1:, 4] = rng.integers(0, 3, size=n - 1)
+    t[1:, 5:8] = rng.uniform(0.3, 1.0, size=(n - 1, 3))
+    for k in range(1, n):
+        if t[k, 4] == R.METAL: t[k, 8] = rng.choice([0.0, 0.4])
+        elif t[k, 4] == R.DIELECTRIC: t[k, 8] = 1.5; t[k, 5:8] = 1.0
+    table = np.asarray(t, dtype=np.float32).astype(np.float64)
+    rt.upload_scene(table)
+    scene = O.SceneArrays.from_table(table)
+    for W, H, S, cap in ((6, 6, 1, 50), (9, 5, 1, 50), (1, 1, 3, 50), (40, 3, 2, 50), (64, 10, 1, 17), (33, 17, 2, 50)):
+        ocam = O.make_camera((9.0, 2.0, 7.0), (0.0, 0.0, 0.0), (0.0, 1.0, 0.0), 50.0, np.float32(W) / np.float32(H), 0.2, 9.0)
+        pod = R.CameraPod()
+        for dst, src in (("origin", "origin"), ("lower_left_corner", "llc"), ("horizontal", "horiz"), ("vertical", "vert"), ("u", "u"), ("v", "v"), ("w", "w")):
+            vec = getattr(ocam, src)
+            getattr(pod, dst)[:] = [vec.x, vec.y, vec.z]
+        pod.lens_radius = ocam.lens_radius
+        rt.set_camera(pod)
+        try:
+            O.lib().orc_set_max_depth(cap)
+            want, wq, wrays, wcount = O.render_counted(scene, ocam, W, H, S, O.usrc_philox(300 + W))
+        finally:
+            O.lib().orc_set_max_depth(50)
+        assert wrays > 0.8 * W * H * S * (cap + 1), "the shell is meant to keep (nearly) every path alive to the depth cap"
+        rgb, irgb, rays, _ = rt.render(rt.params(W, H, S, seed=300 + W, max_depth=cap))
+        assert rays == wrays and rt.counters() == wcount, (W, H, S, cap)
+        assert mismatch(rgb, want) == 0 and np.array_equal(irgb, wq), (W, H, S, cap)
+    # more paths than one block holds, several blocks, ragged edges: against the per-pixel kernel
+    for W, H, S in ((96, 64, 3), (250, 130, 1)):
+        ocam = O.make_camera((9.0, 2.0, 7.0), (0.0, 0.0, 0.0), (0.0, 1.0, 0.0), 50.0, np.float32(W) / np.float32(H), 0.2, 9.0)
+        pod = R.CameraPod()
+        for dst, src in (("origin", "origin"), ("lower_left_corner", "llc"), ("horizontal", "horiz"), ("vertical", "vert"), ("u", "u"), ("v", "v"), ("w", "w")):
+            vec = getattr(ocam, src)
+            getattr(pod, dst)[:] = [vec.x, vec.y, vec.z]
+        pod.lens_radius = ocam.lens_radius
+        rt.set_camera(pod)
+        a, ai, ra, _ = rt.render(rt.params(W, H, S, seed=5, mode=R.MODE_MEGAKERNEL))
+        ca = rt.counters()
+        b, bi, rb, _ = rt.render(rt.params(W, H, S, seed=5, mode=R.MODE_PIXEL))
+        assert ra == rb and ca == rt.counters() and mismatch(a, b) == 0 and np.array_equal(ai, bi), (W, H, S)
+
+
 def test_camera_rays_through_tile_lists_equal_the_full_sweep(rt, monkeypatch):
     """By default the first level of Color() (main.cpp:13-39) for a camera ray is worked out against the list of spheres that the
     rays of its 8x8 tile can reach; RT_AMD_PRIMARY=sweep (read when a context is created) sweeps camera rays like every other

@@ -19,7 +19,7 @@ rt = R.Renderer(0)
 rt.upload_scene(R.final_scene_table())
 rt.set_camera(R.final_camera(1200, 800))
 L = R.load_library()
-buf = np.zeros((8, 8192), dtype=np.uint64)
+buf = np.zeros((10, 8192), dtype=np.uint64)
 for rep in range(2):
     band = next(b for b in (8, 4, 2, 1) if (800 // b) % ranks == 0)
     if os.environ.get("RT_SHARE_TILES") == "1":          # rank 0's TILE share instead of its row bands
@@ -50,6 +50,16 @@ print("sparse trips: total %d, mean %.2f us per trip; waves with > 20 sparse tri
 fs = (buf[6][live].astype(np.int64) - int(t0)) / 100.0
 fd = (buf[7][live].astype(np.int64) - int(t0)) / 100.0
 print("first sweep starts us: min %.0f median %.0f max %.0f;  second trip's sweep starts us: median %.0f max %.0f" % (fs.min(), np.median(fs), fs.max(), np.median(fd), fd.max()))
+# the end shared by the waves of a block (k_trace with RT_TAIL_PATHS > 0): when it begins, how long it lasts, how many bounces it makes
+sh = buf[8][live].astype(np.int64)
+if (sh > 0).any():
+    began = (sh[sh > 0] - int(t0)) / 100.0
+    lasted = exit_[sh > 0] - began
+    nb = buf[9][live][sh > 0].astype(np.float64)
+    print("shared end: begins us: min %.0f median %.0f p90 %.0f max %.0f;  lasts us: median %.0f p90 %.0f max %.0f;  bounces: median %.0f p90 %.0f max %.0f;  us per bounce: median %.1f" %
+          (began.min(), np.median(began), np.percentile(began, 90), began.max(), np.median(lasted), np.percentile(lasted, 90), lasted.max(),
+           np.median(nb), np.percentile(nb, 90), nb.max(), np.median(lasted[nb > 0] / nb[nb > 0])))
+    print("            from the counter running dry to the shared end us: median %.0f p90 %.0f max %.0f" % tuple(np.percentile(began - dry[sh > 0], [50, 90, 100])))
 # the stragglers: for the waves that exit last, how the time after the counter ran dry splits into trips with the ordinary sweep and trips with the sparse one
 order = np.argsort(-exit_)[:12]
 print("last waves: exit us | dry us | trips after dry | of them sparse | us in sparse trips | us in ordinary trips | us per ordinary trip")
