@@ -759,10 +759,22 @@ __device__ __forceinline__ bool shade_step(RayD& ray, int& depth, float closest,
         T.mark(6);
     } else {
         sample = sky(ray.d);
-        for (int k = kNoStack ? -1 : depth - 1; k >= 0; --k) {
-            const int h = stack.at(k);
-            const float4 m = kLds ? s_mat[h] : g_mat[h];
-            sample = mk(m.x, m.y, m.z) * sample;
+        // The attenuation chain, innermost first.  Two levels per round: their stack entries are requested together, then their
+        // albedos, then the products are formed in order -- one memory latency per round instead of one per level (a level below
+        // the first re-reads level 0 and is not multiplied in).  Config 3 with 1 / 2 / 4 / 8 levels per round: 68.5 / 68.3 / 68.5 / 69.0 ms.
+#ifndef RT_REPLAY_GROUP
+#define RT_REPLAY_GROUP 2
+#endif
+#pragma clang loop unroll(disable)
+        for (int k = kNoStack ? -1 : depth - 1; k >= 0; k -= RT_REPLAY_GROUP) {
+            int h[RT_REPLAY_GROUP];
+#pragma unroll
+            for (int j = 0; j < RT_REPLAY_GROUP; ++j) h[j] = stack.at(k - j >= 0 ? k - j : 0);
+            float4 m[RT_REPLAY_GROUP];
+#pragma unroll
+            for (int j = 0; j < RT_REPLAY_GROUP; ++j) m[j] = kLds ? s_mat[h[j]] : g_mat[h[j]];
+#pragma unroll
+            for (int j = 0; j < RT_REPLAY_GROUP; ++j) if (k - j >= 0) sample = mk(m[j].x, m[j].y, m[j].z) * sample;
         }
     }
     return done;
