@@ -453,7 +453,9 @@ __global__ void __launch_bounds__(trace_block(kMfma)) RT_TRACE_WAVES(kBvh, kLds)
         for (int i = threadIdx.x; i < a_words; i += kTraceBlock) s_arec[i] = a.arec[i];
     }
     ExactLds exact_lds{ s_geom, s_aux, nullptr }; exact_lds.arec = s_arec;
-    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    // (the wave's number as a scalar: everything derived from it -- the first chunk, and with it the whole bookkeeping of the
+    // hand-out -- is then uniform for the compiler too, and lives in scalar registers behind scalar branches)
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), lane = threadIdx.x & 63;
     // Per-lane filter masks of one super-chunk: word w of lane l at mask_words[w * 64] (lanes contiguous).
     char* lds_after_scene = reinterpret_cast<char*>(scene_lds) + (kLds ? (size_t)a.n * kLdsBytesPerSphere : 0) + (size_t)a_words * sizeof(uint2);
     // (In RT_MODE_BVH the same area holds each lane's stack of pending nodes instead.)
