@@ -62,6 +62,7 @@ int rt_create(int device_ordinal, rt_context** out)
     { const char* f = getenv("RT_AMD_QUEUE_KB"); const long long kb = f ? atoll(f) : 0; if (kb > 0) ctx->queue_cap = (uint64_t)kb << 10; }
     { const char* f = getenv("RT_AMD_TILE_ORDER"); ctx->tile_ordering = !(f && strcmp(f, "image") == 0); }
     { const char* f = getenv("RT_AMD_PRIMARY"); ctx->primary_lists = !(f && strcmp(f, "sweep") == 0); }
+    { const char* f = getenv("RT_AMD_LARGE_SCENES"); ctx->operand_tiles = f && strcmp(f, "tiles") == 0; }
     hipError_t e = hipSetDevice(device_ordinal);
     if (e == hipSuccess) e = hipMalloc(&ctx->d_rays, 3 * sizeof(unsigned long long));
     if (e == hipSuccess) e = hipMalloc(&ctx->d_work, sizeof(unsigned int));

@@ -38,6 +38,7 @@ struct rt_context {
     bool tile_ordering = true;
     uint32_t* d_tile_lists = nullptr; size_t tile_list_cap = 0;    // per tile: the spheres its camera rays can meet (k_tile_lists)
     bool primary_lists = true;
+    bool operand_tiles = false;         // scenes too large for LDS: the filter's operands as LDS tiles that a block stages for its twelve waves (RT_AMD_LARGE_SCENES=tiles); default: every wave streams them from L2, which measures 13 % faster on 20 000 spheres
     // the order depends on scene, camera and the rows rendered only: it is kept for repeated calls (new seeds, more samples)
     struct TileKey { uint64_t scene_version, camera_version; int32_t width, height, band_rows, band_first, band_step; float tmin; } tile_key{};
     bool tile_key_valid = false; uint64_t scene_version = 0, camera_version = 0;
@@ -76,7 +77,7 @@ struct RenderFrame {
 };
 struct SampleBatch { int index, s0, sc; };
 // What trace_prepare settles once per call for the batches of k_trace.
-struct TracePlan { bool lds, plane, bvh, mfma, ordered; int queue; size_t shmem; int blocks_per_cu, block; };
+struct TracePlan { bool lds, plane, bvh, mfma, ordered, tiled; int queue; size_t shmem; int blocks_per_cu, block; };
 
 #define RT_HIDDEN __attribute__((visibility("hidden")))
 int pixel_render(rt_context* ctx, const RenderFrame& f) RT_HIDDEN;                                              // rt_pixel.hip

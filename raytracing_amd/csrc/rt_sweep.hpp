@@ -163,10 +163,35 @@ __device__ __forceinline__ uint32_t bf16_bits(float x)
 #ifndef RT_PASSA_ADDR
 #define RT_PASSA_ADDR 1
 #endif
-template <bool kLds, bool kPlane, bool kPacked, bool kMfma = false>
-__device__ __forceinline__ void closest_hit(const RayD& ray, float tmin, const SweepScene& sw, const ExactLds& lds,
-                                            uint32_t* mask_words, float& closest, int& hit, SecTimer& T, bool active = true, int prio_after = 0)
+// Large scenes, LDS-tiled (kTiled; k_trace only): the matrix-pipe filter's operands of one super-chunk -- 512 spheres, 8 KB -- are a
+// TILE that the block stages in LDS once for its twelve waves, instead of every wave streaming all of them from L2 for itself.
+// Two tile buffers; the waves of a block sweep in step: at the top of every super-chunk they wait for the tile that was requested
+// one super-chunk earlier (global_load_lds: memory to LDS without passing through registers), meet at a barrier, and request the
+// next one into the other buffer -- cyclically, the first tile of the next sweep behind the last of this one, so that the
+// sequence of buffers never breaks (`tiles_done` counts tiles over the whole launch; tile g lies in buffer g & 1).  The caller
+// has done wait, barrier and count for the first super-chunk of the sweep.  A tile is requested by the block's first eight waves,
+// 16 bytes per lane; chunks beyond the scene's last are not requested (and never read).
+constexpr int kTileSpheres = 32 * 16;                 // one super-chunk
+constexpr int kTileEntries = kTileSpheres / 32 * 64;  // uint2 entries per tile buffer (8 KB)
+__device__ __forceinline__ void stage_operand_tile(const SweepScene& sw, const uint2* tile_buffers, int tile, uint32_t buffer)
 {
+    typedef __attribute__((address_space(1))) const void* GlobalPtr;
+    typedef __attribute__((address_space(3))) void* LdsPtr;
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    if (wave < kTileEntries * 8 / (64 * 16)) {
+        const int lane = threadIdx.x & 63;
+        const int chunk = tile * (kTileSpheres / 32) + wave * 2 + (lane >> 5);          // 32 lanes x 16 bytes = one chunk's 512 bytes
+        if (chunk < ((sw.n + 31) >> 5))
+            __builtin_amdgcn_global_load_lds((GlobalPtr)(reinterpret_cast<const char*>(sw.arec) + (size_t)tile * (kTileEntries * 8) + (size_t)(wave * 64 + lane) * 16),
+                                             (LdsPtr)(reinterpret_cast<const char*>(tile_buffers) + (size_t)buffer * (kTileEntries * 8) + (size_t)wave * 1024), 16, 0, 0);
+    }
+}
+template <bool kLds, bool kPlane, bool kPacked, bool kMfma = false, bool kTiled = false>
+__device__ __forceinline__ void closest_hit(const RayD& ray, float tmin, const SweepScene& sw, const ExactLds& lds,
+                                            uint32_t* mask_words, float& closest, int& hit, SecTimer& T, bool active = true, int prio_after = 0,
+                                            uint32_t* tiles_done = nullptr)
+{
+    static_assert(!kTiled || (kMfma && !kLds), "operand tiles are for the matrix-pipe filter of scenes whose records do not fit LDS");
     // prio_after (wave-uniform, matrix-pipe form only): the filter loop is a long run of independent instructions that can fill any
     // issue slot, the exact passes and the shading that follow are chains of dependent ones; the wave drops to issue priority 0 for
     // the filter and returns to prio_after behind it, so that on a SIMD the waves in their latency-bound sections issue first and
@@ -364,6 +389,16 @@ __device__ __forceinline__ void closest_hit(const RayD& ray, float tmin, const S
     // sphere order and runs the exact test of sphere.cpp:15-52 with the shrinking upper bound of
     // hittablelist.cpp:21-29 (unfused arithmetic).
     for (int sbase = 0; sbase < sw.n_pad; sbase += 32 * kSuperChunkWords) {
+        if constexpr (kTiled) {
+            static_assert(32 * kSuperChunkWords == kTileSpheres, "a tile is a super-chunk");
+            if (sbase != 0) {
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                __syncthreads();
+                ++*tiles_done;
+            }
+            const int next_tile = sbase + kTileSpheres < sw.n_pad ? (sbase >> 9) + 1 : 0;
+            stage_operand_tile(sw, lds.arec, next_tile, (*tiles_done + 1u) & 1u);
+        }
         uint32_t nz = 0u;          // bit (31 - w) set: word w of this super-chunk has a survivor
         int words = 0;
         int base = sbase;
@@ -378,7 +413,8 @@ __device__ __forceinline__ void closest_hit(const RayD& ray, float tmin, const S
         if constexpr (kMfma) {
             // one matrix-pipe chunk per mask word, the operand of the next chunk requested before this one is worked on
             const int words_here = (send - sbase + 31) >> 5;
-            const uint2* ap = (kLds ? lds.arec : sw.arec) + (size_t)(sbase >> 5) * 64 + (threadIdx.x & 63u);
+            const uint2* ap = kTiled ? lds.arec + (size_t)(*tiles_done & 1u) * kTileEntries + (threadIdx.x & 63u)
+                                     : (kLds ? lds.arec : sw.arec) + (size_t)(sbase >> 5) * 64 + (threadIdx.x & 63u);
             uint2 a_next = ap[0];
             uint32_t seen = 0u;
             set_wave_priority(0);

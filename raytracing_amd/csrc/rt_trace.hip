@@ -424,9 +424,10 @@ __device__ __forceinline__ uint32_t lds_word_now(const uint32_t* p)
     typedef volatile __attribute__((address_space(3))) uint32_t LdsWord;
     return *(LdsWord*)p;
 }
-template <bool kLds, bool kPlane, bool kBvh = false, bool kMfma = false, int kQueue = 0>
+template <bool kLds, bool kPlane, bool kBvh = false, bool kMfma = false, int kQueue = 0, bool kTiled = false>
 __global__ void __launch_bounds__(trace_block(kMfma)) RT_TRACE_WAVES(kBvh, kLds) k_trace(const TraceArgs a)
 {
+    static_assert(!kTiled || (kMfma && !kLds && !kBvh), "operand tiles: matrix-pipe filter, scene records not in LDS");
     constexpr int kTraceBlock = trace_block(kMfma);       // (shadows the 512 of the other kernels inside this one)
 #ifndef RT_ITEM_IN_LDS
 #define RT_ITEM_IN_LDS 1
@@ -440,9 +441,11 @@ __global__ void __launch_bounds__(trace_block(kMfma)) RT_TRACE_WAVES(kBvh, kLds)
     // control words come first, at addresses known when the kernel is compiled (no register holds them): [0] = (waves of this block
     // that can get no more items) << 16 | paths those waves hold, [1..3] = number of entries of the three rotating path tables,
     // [4 + w] = paths wave w has announced, [16 + w] = which bounce of the shared end wave w is in (kTailIdle: not in it).
-    constexpr bool kTail = kMfma && !kBvh && kTailPaths > 0;
+    // (With operand tiles -- kTiled, see closest_hit -- the waves of a block sweep in step from the first trip to the last; there
+    // the words count the waves that are done for good, [0], and remember which have said so, [4 + w].)
+    constexpr bool kTail = kMfma && !kBvh && !kTiled && kTailPaths > 0;
     uint32_t* tail_ctl = reinterpret_cast<uint32_t*>(smem);
-    float4* scene_lds = smem + (kTail ? kTailCtlBytes / 16 : 0);
+    float4* scene_lds = smem + (kTail || kTiled ? kTailCtlBytes / 16 : 0);
     float4* s_geom = scene_lds;
     float4* s_mat = scene_lds + (kLds ? a.n : 0);
     Aux* s_aux = reinterpret_cast<Aux*>(scene_lds + (kLds ? 2 * a.n : 0));
@@ -477,7 +480,15 @@ __global__ void __launch_bounds__(trace_block(kMfma)) RT_TRACE_WAVES(kBvh, kLds)
     static_assert(!kTail || kTailPaths <= kFewPaths * (kTraceBlock / 64), "a wave's share of the pooled paths must stay with the sparse sweep: the tables lie in the mask words");
     static_assert(!kTail || 2 * kTailFields * kTailPaths <= kSuperChunkWords * 64, "both path tables lie in the mask words of the block's first wave");
     uint32_t* stack_owner = item_slot + 32;
-    if (kTail && threadIdx.x < kTailCtlBytes / 4) tail_ctl[threadIdx.x] = threadIdx.x < 4 ? 0u : kTailIdle;
+    if ((kTail || kTiled) && threadIdx.x < kTailCtlBytes / 4) tail_ctl[threadIdx.x] = threadIdx.x < 4 ? 0u : kTailIdle;
+    // operand tiles: two buffers behind the waves' mask and item words; the first tile of the first sweep is requested here
+    uint2* tile_buffers = reinterpret_cast<uint2*>(lds_after_scene + (size_t)(kTraceBlock / 64) * (kWordsPerLane + (kMfma ? 1 : 0)) * 64 * sizeof(uint32_t));
+    uint32_t tiles_done = 0u;                  // wave-uniform: tiles swept so far (tile g lies in buffer g & 1)
+    if constexpr (kTiled) {
+        SweepScene sw0; sw0.arec = a.arec; sw0.n = a.n;
+        stage_operand_tile(sw0, tile_buffers, 0, 1u);
+        exact_lds.arec = tile_buffers;
+    }
     __syncthreads();
     // The recursion's attenuation chain is replayed innermost-first when a path reaches the sky, so
     // each lane keeps the indices of the spheres it bounced off.  One 2-byte store per bounce and a
@@ -700,6 +711,19 @@ __global__ void __launch_bounds__(trace_block(kMfma)) RT_TRACE_WAVES(kBvh, kLds)
                 }
             }
         }
+        if constexpr (kTiled) {
+            // Every wave of the block makes every trip, with or without paths (the sweep's barriers need all twelve), until all of
+            // them are done for good.  A wave says so once; the count is read behind the barrier that opens the sweep, and no wave
+            // can add to it between that barrier and the next trip's (it would have to finish this sweep first, which needs every
+            // wave at the barriers inside it), so all twelve read the same number and leave together.
+            if (exhausted && pool_next == pool_end && !__any(active)) {
+                if (lane == 0 && tail_ctl[4 + wave] == kTailIdle) { tail_ctl[4 + wave] = 0u; atomicAdd(tail_ctl, 1u); }
+            }
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // the first tile of this sweep, requested during the last super-chunk of the sweep before
+            __syncthreads();
+            ++tiles_done;
+            if ((uint32_t)__builtin_amdgcn_readfirstlane((int)lds_word_now(tail_ctl)) == (uint32_t)(kTraceBlock / 64)) break;
+        } else
         if (!__any(active)) {
             if (kTail && tail_bounce != kTailIdle) { __syncthreads(); continue; }
             if (exhausted && pool_next == pool_end) break;
@@ -726,6 +750,7 @@ __global__ void __launch_bounds__(trace_block(kMfma)) RT_TRACE_WAVES(kBvh, kLds)
         else if (t_first_done == 0) t_first_done = __builtin_amdgcn_s_memrealtime();
 #endif
         if (kBvh) { if (active) closest_hit_bvh<kLds>(ray, a.tmin, a.bvh, exact_lds, mask_words, closest, hit); }
+        else if constexpr (kTiled) closest_hit<kLds, true, true, true, true>(ray, a.tmin, sw, exact_lds, mask_words, closest, hit, T, active, prio_other, &tiles_done);       // every wave, every trip
         else if (__popcll(live) <= kFewPaths) closest_hit_few<kLds>(ray, a.tmin, sw, exact_lds, live, lane, closest, hit);
         else if constexpr (kMfma) closest_hit<kLds, true, true, true>(ray, a.tmin, sw, exact_lds, mask_words, closest, hit, T, active, prio_other);     // the whole wave enters
         else if (active) closest_hit<kLds, kPlane, true>(ray, a.tmin, sw, exact_lds, mask_words, closest, hit, T);
@@ -865,6 +890,7 @@ namespace {
 using TraceKernel = void (*)(const TraceArgs);
 TraceKernel trace_kernel(const TracePlan& t)
 {
+    if (t.tiled) return t.queue == 2 ? k_trace<false, true, false, true, 2, true> : k_trace<false, true, false, true, 1, true>;
     if (t.queue == 1) {
         if (t.mfma) return t.lds ? k_trace<true, true, false, true, 1> : k_trace<false, true, false, true, 1>;
         if (t.bvh) return t.lds ? k_trace<true, true, true, false, 1> : k_trace<false, true, true, false, 1>;
@@ -947,8 +973,13 @@ int trace_prepare(rt_context* ctx, const RenderFrame& f, TracePlan* plan)
     // the records stay in LDS only while two blocks fit.
     if (t.mfma && t.lds && ctx->max_lds_spheres == 0 &&
         (size_t)ctx->n * kLdsBytesPerSphere + (size_t)((ctx->n + 31) / 32) * 512 + (size_t)(t.block / 64) * kSuperChunkWords * 64 * sizeof(uint32_t) + (size_t)t.block * sizeof(uint32_t) + (kTailPaths > 0 ? kTailCtlBytes : 0) > 80u * 1024u) t.lds = false;
-    t.shmem = (t.lds ? (size_t)ctx->n * kLdsBytesPerSphere + (t.mfma ? (size_t)((ctx->n + 31) / 32) * 512 : 0) : 0) + (size_t)(t.block / 64) * (t.bvh ? kBvhStack : kSuperChunkWords) * 64 * sizeof(uint32_t) + (t.mfma ? (size_t)t.block * sizeof(uint32_t) + (kTailPaths > 0 ? kTailCtlBytes : 0) : 0);
-    int& bpc = ctx->trace_blocks_per_cu[t.queue * 8 + (t.mfma ? (t.lds ? 7 : 6) : t.bvh ? (t.lds ? 5 : 4) : (t.lds ? 1 : 0) + (t.plane ? 2 : 0))];
+    // Scenes whose records do not fit LDS: every wave streams the matrix-pipe filter's operands from L2 for itself (default), or
+    // -- RT_AMD_LARGE_SCENES=tiles when the context is created -- a block stages them in LDS as tiles of 512 spheres for its twelve
+    // waves, which then sweep in step (closest_hit, kTiled).  Same images; 20 000 spheres at 1920x1080x32: 197 ms streamed, 225 ms
+    // tiled (the barrier per tile costs the waves more than the shared operands save: L2 serves the stream at a 99 % hit rate)
+    t.tiled = t.mfma && !t.lds && t.queue != 0 && ctx->operand_tiles;
+    t.shmem = (t.lds ? (size_t)ctx->n * kLdsBytesPerSphere + (t.mfma ? (size_t)((ctx->n + 31) / 32) * 512 : 0) : 0) + (size_t)(t.block / 64) * (t.bvh ? kBvhStack : kSuperChunkWords) * 64 * sizeof(uint32_t) + (t.mfma ? (size_t)t.block * sizeof(uint32_t) + (kTailPaths > 0 || t.tiled ? kTailCtlBytes : 0) : 0) + (t.tiled ? 2u * kTileEntries * sizeof(uint2) : 0);
+    int& bpc = ctx->trace_blocks_per_cu[t.queue * 8 + (t.tiled ? 3 : t.mfma ? (t.lds ? 7 : 6) : t.bvh ? (t.lds ? 5 : 4) : (t.lds ? 1 : 0) + (t.plane ? 2 : 0))];
     if (bpc == 0) {
         int nb = 0;
         hipError_t e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, trace_kernel(t), t.block, t.shmem);

@@ -286,6 +286,47 @@ def test_stress_scene_rows_match_oracle(rt):
     assert same(both[0], both[1]) and same(both[0], both[2]) and same(both[0], both[3])
 
 
+def test_large_scene_operand_tiles_in_lds(rt, monkeypatch):
+    """Scenes whose records do not fit LDS, with the matrix-pipe filter's operands staged in LDS as tiles of 512 spheres that
+    the twelve waves of a block share and sweep in step (RT_AMD_LARGE_SCENES=tiles; the default streams them from L2 per wave):
+    config 5's 20 000 spheres against the oracle, scenes around the tile and chunk boundaries against the default form, and
+    small scenes forced off the LDS mirror (one tile, two tiles, a last chunk that is not full)."""
+    monkeypatch.setenv("RT_AMD_LARGE_SCENES", "tiles")
+    tiled = R.Renderer(0, camera_ray_lists=rt.camera_ray_lists)
+    table = R.scene_grid(42, 75, 19996)
+    tiled.upload_scene(table)
+    tiled.set_camera(R.final_camera(1920, 1080))
+    p = tiled.params(1920, 1080, 1, seed=4, band_rows=2, band_first=350, band_step=10000)
+    rgb, irgb, rays, _ = tiled.render(p)
+    want, wq, wrays = O.render(O.SceneArrays.from_table(table), O.final_camera(1920, 1080), 1920, 1080, 1, O.usrc_philox(4), 1080 - 702, 1080 - 700, fast=False)
+    assert rays == wrays and same(rgb, want) and np.array_equal(irgb, wq)
+    rt.upload_scene(table)
+    rt.set_camera(R.final_camera(1920, 1080))
+    pb = dict(seed=9, band_rows=40, band_first=3, band_step=9)
+    a, b = tiled.render(tiled.params(1920, 1080, 2, **pb)), rt.render(rt.params(1920, 1080, 2, **pb))
+    assert a[2] == b[2] and mismatch(a[0], b[0]) == 0 and np.array_equal(a[1], b[1])
+    rng = np.random.default_rng(99)
+    for n in (522, 544, 545, 1023, 1024, 1025, 1537, 4097):
+        table = _random_scene(rng, n)
+        for r in (tiled, rt):
+            r.upload_scene(table)
+            r.set_camera(R.final_camera(72, 40))
+        a, b = tiled.render(tiled.params(72, 40, 3, seed=n)), rt.render(rt.params(72, 40, 3, seed=n))
+        assert a[2] == b[2] and tiled.counters() == rt.counters() and mismatch(a[0], b[0]) == 0 and np.array_equal(a[1], b[1]), n
+    tiled.close()
+    # the same kernel on small scenes (their records kept out of LDS): a single tile, a partly filled last chunk
+    monkeypatch.setenv("RT_AMD_MAX_LDS_SPHERES", "16")
+    small = R.Renderer(0, camera_ray_lists=rt.camera_ray_lists)
+    for n in (20, 33, 487, 512, 513):
+        table = R.final_scene_table()[:n] if n <= 487 else _random_scene(rng, n)
+        for r in (small, rt):
+            r.upload_scene(table)
+            r.set_camera(R.final_camera(72, 40))
+        a, b = small.render(small.params(72, 40, 3, seed=n)), rt.render(rt.params(72, 40, 3, seed=n))
+        assert a[2] == b[2] and mismatch(a[0], b[0]) == 0 and np.array_equal(a[1], b[1]), n
+    small.close()
+
+
 def test_filter_variants_agree(rt, monkeypatch):
     """The plane pre-filter on the matrix pipe (default), the same filter on the vector ALU and the full-discriminant
     filter are all conservative: same image, same ray count as the literal kernel.  Near the horizon the reference's own
