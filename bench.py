@@ -163,6 +163,9 @@ def parse_args(argv):
     ap.add_argument("--mode", default="megakernel", choices=["megakernel", "wavefront", "pixel", "bvh"])
     ap.add_argument("--rehearse-on-one-gpu", action="store_true",
                     help="debug: all ranks share GPU 0 and gather over gloo (RCCL refuses two ranks on one device)")
+    ap.add_argument("--no-overlap", action="store_true",
+                    help="several GPUs, row bands: wait for every step's gather before the next step's kernels start (default: the gather of "
+                         "step k runs on the collective's stream while step k + 1 renders into a second buffer)")
     ap.add_argument("--dry-run", action="store_true",
                     help="no GPU: the ranks start, gather synthetic rows over gloo and rank 0 checks the assembled image (launcher, "
                          "partition and gather without the render kernels)")
@@ -209,9 +212,9 @@ def dry_run(args, rank, world):
             l = (yy % 8) * 8 + xx % 8
             want = ((tid[..., None] * 7 + l[..., None] + torch.arange(3)[None, None, :]) % 256).to(torch.int32)
             ok = bool(torch.equal(img, want))
-            print(json.dumps({"metric": "Mrays/s (1200x800 RTOW final scene)", "value": None, "unit": "Mrays/s", "n_gpus": world, "dry_run": True,
+            emit({"metric": "Mrays/s (1200x800 RTOW final scene)", "value": None, "unit": "Mrays/s", "n_gpus": world, "dry_run": True,
                               "ranks_reported_by_backend": dist.get_world_size() if world > 1 else 1, "backend": "gloo" if world > 1 else None,
-                              "assembled_image_ok": ok, "gather_ms": gather_ms, "config": {"workload": args.workload, "partition": "tiles"}}), flush=True)
+                              "assembled_image_ok": ok, "gather_ms": gather_ms, "config": {"workload": args.workload, "partition": "tiles"}})
             if not ok:
                 raise SystemExit("dry run: the gathered image is not the expected one")
         if world > 1:
@@ -230,9 +233,9 @@ def dry_run(args, rank, world):
     if rank == 0:
         want = (torch.arange(height, dtype=torch.int32)[:, None, None] * 7 + torch.arange(3, dtype=torch.int32)[None, None, :]) % 256
         ok = bool(torch.equal(img, want.expand(height, width, 3)))
-        print(json.dumps({"metric": "Mrays/s (1200x800 RTOW final scene)", "value": None, "unit": "Mrays/s", "n_gpus": world, "dry_run": True,
+        emit({"metric": "Mrays/s (1200x800 RTOW final scene)", "value": None, "unit": "Mrays/s", "n_gpus": world, "dry_run": True,
                           "ranks_reported_by_backend": dist.get_world_size() if world > 1 else 1, "backend": "gloo" if world > 1 else None,
-                          "assembled_image_ok": ok, "gather_ms": gather_ms, "config": {"workload": args.workload, "band_rows": band}}), flush=True)
+                          "assembled_image_ok": ok, "gather_ms": gather_ms, "config": {"workload": args.workload, "band_rows": band}})
         if not ok:
             raise SystemExit("dry run: the gathered image is not the expected one")
     if world > 1:
@@ -293,11 +296,35 @@ def roofline_block(args, n_spheres, rays_per_launch, kernel_ms, prof):
     return block
 
 
+_RESULT_FD = None
+
+
+def keep_stdout_for_the_result():
+    """The contract is ONE JSON line on stdout.  Libraries loaded further down write there too (RCCL prints a version banner
+    to stdout when a process group is created): from here on file descriptor 1 leads to stderr, and emit() writes the result line
+    to the descriptor that was stdout."""
+    global _RESULT_FD
+    if _RESULT_FD is None:
+        sys.stdout.flush()
+        _RESULT_FD = os.dup(1)
+        os.dup2(2, 1)
+
+
+def emit(line):
+    data = (json.dumps(line) + "\n").encode()
+    sys.stdout.flush()
+    if _RESULT_FD is None:
+        os.write(1, data)
+    else:
+        os.write(_RESULT_FD, data)
+
+
 def main(argv=None):
     argv = sys.argv[1:] if argv is None else argv
     args = parse_args(argv)
     if "WORLD_SIZE" not in os.environ and args.gpus > 1:
         raise SystemExit(self_launch(args, argv))
+    keep_stdout_for_the_result()
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -413,18 +440,63 @@ def main(argv=None):
                 gather_ms.append(ev_a.elapsed_time(ev_b))
         return img
 
+    # Several ranks, row bands: the gather of step k overlaps the kernels of step k + 1.  Two output buffers alternate; the gather
+    # is issued asynchronously (it starts on the collective's stream once this step's kernels are done), rank 0 puts the rows in
+    # place on a side stream, and nothing in the loop waits on the host.  A buffer is rendered into again only after the gather
+    # that read it -- two steps earlier -- has finished (a stream-side wait, long satisfied by then).  The steps' kernel and gather
+    # times are measured afterwards, on a few steps run one after the other outside the timed region.
+    overlap = use_dist and not by_tiles and not args.rehearse_on_one_gpu and not args.no_overlap
+    if overlap:
+        outs = [out, torch.zeros_like(out)]
+        recv = [torch.empty((world, pad, width, 3), dtype=torch.int32, device=dev) if rank == 0 else None for _ in range(2)]
+        imgs = [torch.empty((height, width, 3), dtype=torch.int32, device=dev) if rank == 0 else None for _ in range(2)]
+        side = torch.cuda.Stream(device=dev)
+        placed = [torch.cuda.Event(), torch.cuda.Event()]
+        pending = [None, None]
+
+        def step_overlapped(k):
+            b = k & 1
+            if pending[b] is not None:
+                pending[b].wait()                                          # (this stream waits, not the host)
+                if rank == 0:
+                    torch.cuda.current_stream().wait_event(placed[b])     # rank 0 has read recv[b] before it is filled again
+            rt.render_device(p, d_irgb=outs[b].data_ptr(), stream=stream)
+            pending[b] = dist.gather(outs[b], list(recv[b].unbind(0)) if rank == 0 else None, dst=0, async_op=True)
+            if rank == 0:
+                with torch.cuda.stream(side):
+                    pending[b].wait()
+                    torch.index_select(recv[b].view(world * pad, width, 3), 0, idx, out=imgs[b])
+                    placed[b].record(side)
+            return imgs[b]
+
     for _ in range(args.warmup):
         step(False)
     if use_dist:
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    for _ in range(args.steps):
-        img = step(True)
+    if overlap:
+        for k in range(args.steps):
+            img = step_overlapped(k)
+        for w in pending:
+            if w is not None:
+                w.wait()
+    else:
+        for _ in range(args.steps):
+            img = step(True)
     torch.cuda.synchronize()
     if use_dist:
         dist.barrier()
     elapsed = time.perf_counter() - t0
+    if overlap:
+        rays_last, _ = rt.stats()
+        rays_per_step.extend([rays_last] * args.steps)
+        img_overlapped = img
+        for _ in range(min(args.steps, 3)):        # kernel and gather times of single steps, outside the timed region
+            kept = len(rays_per_step)
+            step(True)
+            del rays_per_step[kept:]
+        img = img_overlapped
 
     t = torch.tensor([elapsed, float(sum(rays_per_step)), float(np.mean(kernel_ms)), float(np.max(kernel_ms))], dtype=torch.float64, device=dev)
     per_rank_kernel_ms = [float(np.mean(kernel_ms))]
@@ -463,6 +535,7 @@ def main(argv=None):
             "kernel_ms_per_rank": per_rank_kernel_ms,
             "gather_ms_rank0": float(np.mean(gather_ms)) if gather_ms else None,
             "gather_bytes_per_step": int(out.numel() * 4 * (world - 1)) if world > 1 else 0,
+            "gather_overlaps_next_step": bool(overlap),
             "roofline": roofline_block(args, n_spheres, my_rays, float(np.mean(kernel_ms)), prof),
         }
         if args.mode == "bvh":
@@ -526,7 +599,7 @@ def main(argv=None):
             rt2.close()
         if line["roofline"].get("executed_frac") is not None:
             assert line["roofline"]["executed_frac"] <= 1.0, "executed FP32 rate above the peak: the profile summary under profiles/ does not belong to this kernel"
-        print(json.dumps(line), flush=True)
+        emit(line)
     if use_dist:
         dist.destroy_process_group()
 

@@ -75,9 +75,17 @@ def test_bench_line_through_a_one_rank_nccl_group():
     for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
         env.pop(k, None)
     env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-    proc = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--force-dist", "--workload", "c1", "--steps", "2", "--warmup", "1",
-                           "--no-cpu-baseline", "--no-beyond"], env=env, capture_output=True, text=True, timeout=300)
-    assert proc.returncode == 0, proc.stderr[-2000:]
-    line = json.loads(proc.stdout.strip().splitlines()[-1])
-    assert line["backend"] == "nccl" and line["ranks_reported_by_backend"] == 1 and line["n_gpus"] == 1
-    assert line["gather_ms_rank0"] is not None and line["value"] > 0
+    lines = {}
+    for name, extra in (("overlapped", []), ("step by step", ["--no-overlap"])):
+        # (five steps: the two output buffers of the overlapped form are each used more than once)
+        proc = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--force-dist", "--workload", "c1", "--steps", "5", "--warmup", "1",
+                               "--no-cpu-baseline", "--no-beyond"] + extra, env=env, capture_output=True, text=True, timeout=300)
+        assert proc.returncode == 0, proc.stderr[-2000:]
+        line = json.loads(proc.stdout.strip().splitlines()[-1])
+        assert line["backend"] == "nccl" and line["ranks_reported_by_backend"] == 1 and line["n_gpus"] == 1
+        assert line["gather_ms_rank0"] is not None and line["value"] > 0
+        lines[name] = line
+    # the gather of step k running beside the kernels of step k + 1 changes neither the image nor the ray count
+    assert lines["overlapped"]["gather_overlaps_next_step"] and not lines["step by step"]["gather_overlaps_next_step"]
+    assert lines["overlapped"]["image_checksum"] == lines["step by step"]["image_checksum"]
+    assert lines["overlapped"]["rays_per_sample"] == lines["step by step"]["rays_per_sample"]
