@@ -623,13 +623,13 @@ __device__ __forceinline__ void closest_hit_few(const RayD& ray, float tmin, con
                     desc[j] = b[j] * b[j] - qa * cc;
                 }
             }
-            bool any_positive = false;
+            // ascending sphere index inside the lane, strict comparisons: equal roots stay with the lower index.  The roots of a
+            // group of 64 spheres are worked out only when the line meets one of them (three or four of a scene's eight groups per
+            // ray, the ground sphere's among them): the square root and the two divisions are sixty instructions that the whole
+            // wave issues whether one lane needs them or all
 #pragma unroll
-            for (int j = 0; j < kPerLane; ++j) any_positive = any_positive || desc[j] > 0.0f;
-            if (__any(any_positive)) {
-                // ascending sphere index inside the lane, strict comparisons: equal roots stay with the lower index
-#pragma unroll
-                for (int j = 0; j < kPerLane; ++j) {
+            for (int j = 0; j < kPerLane; ++j) {
+                if (__any(desc[j] > 0.0f)) {
                     if (desc[j] > 0.0f) {
                         const float sq = sqrtf(desc[j]);
                         float temp = (-b[j] - sq) / qa;
