@@ -447,27 +447,11 @@ def main(argv=None):
     # times are measured afterwards, on a few steps run one after the other outside the timed region.
     overlap = use_dist and not by_tiles and not args.rehearse_on_one_gpu and not args.no_overlap
     if overlap:
-        outs = [out, torch.zeros_like(out)]
-        recv = [torch.empty((world, pad, width, 3), dtype=torch.int32, device=dev) if rank == 0 else None for _ in range(2)]
-        imgs = [torch.empty((height, width, 3), dtype=torch.int32, device=dev) if rank == 0 else None for _ in range(2)]
-        side = torch.cuda.Stream(device=dev)
-        placed = [torch.cuda.Event(), torch.cuda.Event()]
-        pending = [None, None]
+        pipe = rdist.RowGatherPipeline(width, height, band, rank, world, device=dev)
 
         def step_overlapped(k):
-            b = k & 1
-            if pending[b] is not None:
-                pending[b].wait()                                          # (this stream waits, not the host)
-                if rank == 0:
-                    torch.cuda.current_stream().wait_event(placed[b])     # rank 0 has read recv[b] before it is filled again
-            rt.render_device(p, d_irgb=outs[b].data_ptr(), stream=stream)
-            pending[b] = dist.gather(outs[b], list(recv[b].unbind(0)) if rank == 0 else None, dst=0, async_op=True)
-            if rank == 0:
-                with torch.cuda.stream(side):
-                    pending[b].wait()
-                    torch.index_select(recv[b].view(world * pad, width, 3), 0, idx, out=imgs[b])
-                    placed[b].record(side)
-            return imgs[b]
+            rt.render_device(p, d_irgb=pipe.buffer(k).data_ptr(), stream=stream)
+            pipe.submit(k)
 
     for _ in range(args.warmup):
         step(False)
@@ -477,10 +461,8 @@ def main(argv=None):
     t0 = time.perf_counter()
     if overlap:
         for k in range(args.steps):
-            img = step_overlapped(k)
-        for w in pending:
-            if w is not None:
-                w.wait()
+            step_overlapped(k)
+        img = pipe.finish()
     else:
         for _ in range(args.steps):
             img = step(True)

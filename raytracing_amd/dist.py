@@ -61,6 +61,83 @@ def gather_rows(local, height, band_rows, rank, world, group=None, src_index=Non
     return None
 
 
+class RowGatherPipeline:
+    """Row bands, several steps in a row: the gather of step k runs beside the rendering of step k + 1.
+
+    Two output buffers alternate.  `buffer(k)` hands out the buffer step k renders into -- first making the caller's stream wait
+    (CUDA) or the host wait (CPU tensors) for the gather that read it two steps earlier; `submit(k)` issues the gather of that buffer
+    asynchronously (on CUDA it starts on the collective's stream once the kernels queued so far on the current stream are done) and,
+    on rank 0, puts the gathered rows in place -- on a side stream for CUDA tensors, so that the current stream goes straight on to
+    the next step; `finish()` waits for everything and returns the last step's image on rank 0 (None elsewhere).  Works over RCCL
+    (backend "nccl") on CUDA tensors and over gloo on CPU tensors."""
+
+    def __init__(self, width, height, band_rows, rank, world, device=None, channels=3, dtype=torch.int32, group=None):
+        self.width, self.height, self.band_rows, self.rank, self.world, self.group = width, height, band_rows, rank, world, group
+        self.pad = max_owned_rows(height, band_rows, world)
+        dev = torch.device("cpu") if device is None else torch.device(device)
+        self.cuda = dev.type == "cuda"
+        self.outs = [torch.zeros((self.pad, width, channels), dtype=dtype, device=dev) for _ in range(2)]
+        root = rank == 0
+        self.recv = [torch.empty((world, self.pad, width, channels), dtype=dtype, device=dev) if root else None for _ in range(2)]
+        self.imgs = [torch.empty((height, width, channels), dtype=dtype, device=dev) if root else None for _ in range(2)]
+        self.idx = row_index(height, band_rows, world, dev) if root else None
+        self.pending = [None, None]
+        self.unplaced = [False, False]          # CPU tensors, rank 0: gathered rows of that buffer not yet put in place
+        self.last = None
+        if self.cuda:
+            self.side = torch.cuda.Stream(device=dev)
+            self.placed = [torch.cuda.Event(), torch.cuda.Event()]
+
+    def _place(self, b):
+        torch.index_select(self.recv[b].view(self.world * self.pad, self.width, -1), 0, self.idx, out=self.imgs[b])
+
+    def _settle(self, b):
+        """The gather of buffer b is over as far as the caller's stream (CUDA) or the host (CPU) is concerned, and rank 0 has read recv[b]."""
+        if self.pending[b] is None:
+            return
+        self.pending[b].wait()
+        if self.rank == 0:
+            if self.cuda:
+                torch.cuda.current_stream().wait_event(self.placed[b])
+            elif self.unplaced[b]:
+                self._place(b)
+                self.unplaced[b] = False
+        self.pending[b] = None
+
+    def buffer(self, k):
+        b = k & 1
+        self._settle(b)
+        return self.outs[b]
+
+    def submit(self, k):
+        b = k & 1
+        self.pending[b] = dist.gather(self.outs[b], list(self.recv[b].unbind(0)) if self.rank == 0 else None, dst=0, group=self.group, async_op=True)
+        if self.rank == 0:
+            if self.cuda:
+                with torch.cuda.stream(self.side):
+                    self.pending[b].wait()
+                    self._place(b)
+                    self.placed[b].record(self.side)
+            else:
+                self.unplaced[b] = True
+        self.last = b
+
+    def image(self, k):
+        """Rank 0: the assembled image of step k (k must be one of the last two steps submitted); waits for it."""
+        b = k & 1
+        self._settle(b)
+        if self.cuda:
+            self.side.synchronize()
+        return self.imgs[b]
+
+    def finish(self):
+        for b in (0, 1):
+            self._settle(b)
+        if self.cuda:
+            self.side.synchronize()
+        return self.imgs[self.last] if self.rank == 0 and self.last is not None else None
+
+
 def render_image(rt, width, height, spp, seed=0, band_rows=8, rank=0, world=1, device=None, out=None, src_index=None,
                  group=None, mode=0):
     """Render this rank's bands with `rt` (a Renderer on this rank's GPU) into a device tensor and gather.

@@ -171,3 +171,54 @@ def test_tile_layout_covers_every_tile_once():
         tiles = torch.cat([t[:n] for (t, _), n in zip(parts, counts)])
         ids = torch.cat([i[:n] for (_, i), n in zip(parts, counts)])
         assert np.array_equal(rdist.assemble_tiles(tiles, ids, width, height).numpy(), img)
+
+
+def _pipeline_worker(rank, world, port, band, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    pipe = rdist.RowGatherPipeline(W, H, band, rank, world)
+    steps, bad = 5, []
+
+    def want(k):
+        return ((torch.arange(H, dtype=torch.int32)[:, None, None] * 7 + k * 1000 + torch.arange(3, dtype=torch.int32)[None, None, :]) % 65521).expand(H, W, 3)
+
+    for k in range(steps):
+        buf = pipe.buffer(k)               # (free again: the gather of step k - 2 has read it)
+        buf.zero_()
+        j = 0
+        for y0, y1 in rdist.owned_bands(H, band, rank, world):
+            buf[j:j + (y1 - y0)] = want(k)[y0:y1]
+            j += y1 - y0
+        pipe.submit(k)
+        if k >= 1:
+            img = pipe.image(k - 1)        # the step before, while this step's gather may still be under way
+            if rank == 0 and not torch.equal(img, want(k - 1)):
+                bad.append(k - 1)
+    last = pipe.finish()
+    if rank == 0:
+        if not torch.equal(last, want(steps - 1)):
+            bad.append(steps - 1)
+        q.put(bad)
+    else:
+        assert last is None
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("band", [1, 8])
+def test_two_rank_pipeline_overlaps_gather_and_next_step(band):
+    """bench.py's several-GPU loop: two output buffers, the gather of step k issued asynchronously while step k + 1 fills the
+    other buffer; every step's assembled image on rank 0 is that step's."""
+    world = 2
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_pipeline_worker, args=(r, world, port, band, q)) for r in range(world)]
+    for pr in procs:
+        pr.start()
+    bad = q.get(timeout=120)
+    for pr in procs:
+        pr.join(timeout=60)
+        assert pr.exitcode == 0
+    assert bad == []
