@@ -447,11 +447,19 @@ def main(argv=None):
     # times are measured afterwards, on a few steps run one after the other outside the timed region.
     overlap = use_dist and not by_tiles and not args.rehearse_on_one_gpu and not args.no_overlap
     if overlap:
-        pipe = rdist.RowGatherPipeline(width, height, band, rank, world, device=dev)
-
         def step_overlapped(k):
             rt.render_device(p, d_irgb=pipe.buffer(k).data_ptr(), stream=stream)
             pipe.submit(k)
+
+        try:
+            # two steps outside the timed region: both buffers, the asynchronous gather and rank 0's side stream have run once.  A
+            # backend that cannot do this fails here, in the same place on every rank, and the steps are then taken one by one.
+            pipe = rdist.RowGatherPipeline(width, height, band, rank, world, device=dev)
+            step_overlapped(0); step_overlapped(1)
+            pipe.finish()
+        except Exception as exc:          # noqa: BLE001 -- whatever the backend raises
+            print(f"bench.py: overlapped gather unavailable ({exc!r}); stepping one by one", file=sys.stderr, flush=True)
+            overlap = False
 
     for _ in range(args.warmup):
         step(False)
