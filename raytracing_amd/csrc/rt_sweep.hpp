@@ -837,6 +837,29 @@ __device__ __forceinline__ uint32_t image_tile(const ItemGeometry& ig, uint32_t 
     const uint32_t pos = (uint32_t)ig.share_first + work_tile * (uint32_t)ig.share_step;
     return ig.tile_order ? ig.tile_order[pos] : pos;
 }
+// The same numbering for a whole row of 64 items at once: `row` = item >> 6 (one tile at one sample) is the same for every lane of
+// a wave that holds such a row, `l` = item & 63 is the lane's pixel of the tile.  With `row` in a scalar register the two
+// divisions by the sample count and the tile-row length, the look-up of the tile order and the band arithmetic of the tile's first
+// pixel row run once per wave on the scalar unit instead of once per lane with quarter-rate integer multiplies.
+__device__ __forceinline__ bool decode_item_row(const ItemGeometry& ig, uint32_t row, uint32_t l, uint32_t& pix, uint32_t& smp, int& i, int& j)
+{
+    const uint32_t work_tile = row / (uint32_t)ig.s_count, s_rel = row - work_tile * (uint32_t)ig.s_count;
+    const uint32_t tile = image_tile(ig, work_tile);
+    const int ty = (int)(tile / (uint32_t)ig.tiles_x), tx = (int)(tile - (uint32_t)ty * (uint32_t)ig.tiles_x);
+    i = tx * 8 + (int)(l & 7u);
+    const int r = ty * 8 + (int)(l >> 3);
+    // owned_row_to_y2 for r = ty * 8 + 0..7: the band of the tile's first row once, then at most one band boundary inside the
+    // tile when a band has eight rows or more (a division per lane otherwise)
+    int band = (ty * 8) / ig.band_rows, in_band = ty * 8 - band * ig.band_rows + (int)(l >> 3);
+    if (ig.band_rows >= 8) { if (in_band >= ig.band_rows) { in_band -= ig.band_rows; ++band; } }
+    else { const int over = in_band / ig.band_rows; band += over; in_band -= over * ig.band_rows; }
+    const int y = (ig.band_first + band * ig.band_step) * ig.band_rows + in_band;
+    if (!(i < ig.width && r < ig.owned_rows && y < ig.height)) return false;
+    j = ig.height - 1 - y;
+    pix = (uint32_t)j * (uint32_t)ig.width + (uint32_t)i;
+    smp = (uint32_t)ig.s_begin + s_rel;
+    return true;
+}
 __device__ __forceinline__ bool decode_item(const ItemGeometry& ig, uint32_t item, uint32_t& pix, uint32_t& smp, int& i, int& j, uint32_t& store)
 {
     const uint32_t ts = item >> 6, l = item & 63u;

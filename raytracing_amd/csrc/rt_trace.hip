@@ -274,9 +274,16 @@ __global__ void __launch_bounds__(256) k_tile_class_from_lists(const uint32_t* l
 constexpr int kQueueFloats = 8;
 constexpr uint32_t kNoSample = 0xffffffffu;        // sample word of a row that holds no ray (padding pixel of an edge tile)
 // A thread takes every gridDim.x * 256-th item: with sixteen items per thread instead of one the camera's constants and the
-// item arithmetic's scalar part are set up once per sixteen rays (3.4 against 3.9 ms for the 240 M camera rays of config 3; the
-// kernel is bound by the vector unit -- 2.5 Philox blocks per wave, the lens sample is drawn by rejection -- the queue's 7.7 GB
-// alone would take 1.1 ms).  Small batches keep enough blocks to fill the chip.
+// item arithmetic's scalar part are set up once per sixteen rays, and the row-wise part of the item arithmetic runs on the scalar
+// unit (decode_item_row): 3.2 against 3.9 ms for the 240 M camera rays of config 3; the queue's 7.7 GB alone would take 1.1 ms,
+// a plain fill runs at 6.9 TB/s here.  Small batches keep enough blocks to fill the chip.
+//
+// The lens sample is drawn by rejection (RandomUnitInDisk, camera.cpp:31-44; one try in 4.7 fails) and the wave retries in place
+// until its unluckiest lane is through: 3.6 tries, 2.5 Philox blocks for all 64 lanes.  Collecting the failed items of several rows
+// on a list in LDS and giving 64 of them their further tries together (1.3 blocks per ray) was built and measured: 5.9 ms.  A
+// row stored with holes leaves the L2 as partly written lines before the holes are filled (2 MB are written per XCD between two
+// rows of a wave), and those, like the 32-byte pieces that fill them later, are far slower to write than whole lines; with the
+// rows stored whole and the pieces stored over them 4.5 ms, with the pieces left out (a lower bound, wrong rays) 2.8 ms.
 constexpr uint32_t kPrimaryItemsPerThread = 16, kPrimaryMinBlocks = 4096;
 __global__ void __launch_bounds__(256) k_primary(const TraceArgs a)
 {
@@ -284,9 +291,10 @@ __global__ void __launch_bounds__(256) k_primary(const TraceArgs a)
     ig.owned_rows = a.owned_rows; ig.tiles_x = a.tiles_x; ig.Q = a.Q; ig.s_begin = a.s_begin; ig.s_count = a.s_count; ig.tile_order = a.tile_order; ig.share_first = a.share_first; ig.share_step = a.share_step;
 #pragma unroll 1
     for (uint32_t it = blockIdx.x * 256u + threadIdx.x; it < a.total_items; it += gridDim.x * 256u) {
-        uint32_t gp = 0u, gs = kNoSample, store = 0u; int i = 0, j = 0;
+        uint32_t gp = 0u, gs = kNoSample; int i = 0, j = 0;
         RayD gr; gr.o = mk(0, 0, 0); gr.d = mk(0, 0, 0);
-        if (decode_item(ig, it, gp, gs, i, j, store)) gr = camera_ray<true>(a.cam, gp, gs, i, j, (float)a.width, (float)a.height, a.k0, a.k1);
+        // (a wave's 64 items are one row of the numbering: blocks of 256 threads, batches of whole rows)
+        if (decode_item_row(ig, (uint32_t)__builtin_amdgcn_readfirstlane((int)(it >> 6)), it & 63u, gp, gs, i, j)) gr = camera_ray<true>(a.cam, gp, gs, i, j, (float)a.width, (float)a.height, a.k0, a.k1);
         else gs = kNoSample;
         v4f ra, rb;
         ra.x = gr.o.x; ra.y = gr.o.y; ra.z = gr.o.z; ra.w = gr.d.x;
@@ -326,9 +334,10 @@ __device__ __forceinline__ uint32_t stage_chunk(const TraceArgs& a, const ItemGe
     uint32_t list_tile = 0xffffffffu, cnt = kNoTileList; int cand = 0; float4 crec = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
     for (uint32_t row = g; row < claim_end; row += 64u) {        // 64 items: one tile at one sample
         const uint32_t it = row + (uint32_t)lane;
-        uint32_t gp = 0xffffffffu, gs = 0u, gstore = 0u; int i = 0, j = 0;
+        uint32_t gp = 0xffffffffu, gs = 0u; int i = 0, j = 0;
+        const uint32_t gstore = it;                    // the sample's slot is the item number
         RayD gr; gr.o = mk(0, 0, 0); gr.d = mk(0, 0, 0);
-        bool keep = decode_item(ig, it, gp, gs, i, j, gstore);         // padding pixels of edge tiles are dropped here
+        bool keep = decode_item_row(ig, (uint32_t)__builtin_amdgcn_readfirstlane((int)(row >> 6)), (uint32_t)lane, gp, gs, i, j);         // padding pixels of edge tiles are dropped here
         if (keep) gr = camera_ray<kWidePhilox>(a.cam, gp, gs, i, j, fnx, fny, a.k0, a.k1);
         T.mark(8);
         // The first level of Color() for the camera ray, here, where the 64 lanes hold the rays of one tile: the closest
