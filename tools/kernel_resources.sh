@@ -29,7 +29,7 @@ for r in rows:
 PY
 done
 s=$tmp/rt_trace-hip-amdgcn-amd-amdhsa-gfx950.s
-awk '/^_Z7k_traceILb1ELb1ELb0ELb1ELi1EEv9TraceArgs:/,/s_endpgm/' $s > $tmp/kt.s
+awk '/^_Z7k_traceILb1ELb1ELb0ELb1ELi1ELb0EEv9TraceArgs:/,/s_endpgm/' $s > $tmp/kt.s
 first_atomic=$(grep -n "global_atomic_add " $tmp/kt.s | head -1 | cut -d: -f1)
 echo "# k_trace<lds, plane, no hierarchy, matrix-pipe filter, rows from k_primary's queue> (the headline variant): $(wc -l < $tmp/kt.s) lines of ISA; the main loop's first hand-out atomic is at line ${first_atomic:-?}, everything before line ~400 is the prologue"
 echo "#   scratch stores at lines: $(grep -n scratch_store $tmp/kt.s | cut -d: -f1 | tr '\n' ' ')"
